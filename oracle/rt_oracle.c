@@ -1139,6 +1139,17 @@ static ray camera_emit(const orc_scene* s, orc_rng* g, double x, double y)   /* 
     return mkray(vadd(s->cam_pos, offset), dir, rnd_range(g, s->shutter0, s->shutter1), 1e-3, ORC_INF);
 }
 
+/* primary rays through the camera on a side x side grid of pixel centres, drawn from the scene's own glibc
+ * stream -- the same calls ref_harness.cpp do_firsthit makes, so the stream position stays in step */
+void orc_primary_rays(orc_scene* s, int side, double* rays7)
+{
+    for (int i = 0; i < side; i++) for (int j = 0; j < side; j++) {
+        ray r = camera_emit(s, &s->rng, (j + 0.5) / side, (i + 0.5) / side);
+        double* w = rays7 + (size_t) (i * side + j) * 7;
+        put3(w, r.o); put3(w + 3, r.d); w[6] = r.time;
+    }
+}
+
 static inline int bad3(v3 c)                                              /* util.hpp:142-151 */
 { return isnan(c.x) || isnan(c.y) || isnan(c.z) || fabs(c.x) == ORC_INF || fabs(c.y) == ORC_INF || fabs(c.z) == ORC_INF; }
 

@@ -1,0 +1,348 @@
+"""ctypes binding of oracle/librt_oracle.so -- TEST INFRASTRUCTURE (checker only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "librt_oracle.so")
+
+TREE_ROW, PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 56, 24, 16, 8
+RNG_GLIBC, RNG_COUNTER = 0, 1
+SPHERE, MSPHERE, PLANEXY, PLANEXZ, PLANEYZ, TRIANGLE = 1, 2, 3, 4, 5, 6
+
+_lib = None
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "rt_oracle.c")
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", ORACLE_DIR, "librt_oracle.so"], check=True, capture_output=True)
+        L = C.CDLL(LIB_PATH)
+        L.orc_scene_new.restype = C.c_void_p
+        L.orc_build_c0.restype = C.c_void_p
+        L.orc_build_mixed.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed"):
+            getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
+        _lib = L
+    return _lib
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+class Scene:
+    """Thin handle over orc_scene*."""
+
+    def __init__(self, handle, width, height):
+        self.h = C.c_void_p(handle)
+        self.width, self.height = width, height
+
+    # ---- constructors
+    @classmethod
+    def new(cls, width, height, seed=1):
+        return cls(lib().orc_scene_new(width, height, seed), width, height)
+
+    @classmethod
+    def c0(cls, width, height, seed=1):
+        return cls(lib().orc_build_c0(width, height, seed), width, height)
+
+    @classmethod
+    def mixed(cls, width, height, seed=1):
+        return cls(lib().orc_build_mixed(width, height, seed), width, height)
+
+    def free(self):
+        if self.h:
+            lib().orc_scene_free(self.h)
+            self.h = None
+
+    # ---- builder API
+    def tex_constant(self, r, g, b):
+        return lib().orc_tex_constant(self.h, C.c_double(r), C.c_double(g), C.c_double(b))
+
+    def tex_checker(self, even, odd):
+        return lib().orc_tex_checker(self.h, even, odd)
+
+    def tex_image(self, pixels, color_based):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        h, w, ch = px.shape
+        return lib().orc_tex_image(self.h, _p(px, C.c_uint8), w, h, ch, int(color_based))
+
+    def mat_lambertian(self, tex):
+        return lib().orc_mat_lambertian(self.h, tex)
+
+    def mat_metal(self, tex, rough):
+        return lib().orc_mat_metal(self.h, tex, C.c_double(rough))
+
+    def mat_dielectric(self, ior):
+        return lib().orc_mat_dielectric(self.h, C.c_double(ior))
+
+    def mat_emissive(self, tex):
+        return lib().orc_mat_emissive(self.h, tex)
+
+    def mat_phong(self, kd, ks, ke, tr, ns, ni, tex=-1):
+        k = (C.c_double * 12)(*[float(x) for x in list(kd) + list(ks) + list(ke) + list(tr)])
+        return lib().orc_mat_phong(self.h, k, C.c_double(ns), C.c_double(ni), tex)
+
+    def add_sphere(self, c, r, mat, flip=0, to_lights=0):
+        return lib().orc_add_sphere(self.h, _d3(c), C.c_double(r), mat, flip, to_lights)
+
+    def add_msphere(self, c0, c1, t0, t1, r, mat, flip=0, to_lights=0):
+        return lib().orc_add_msphere(self.h, _d3(c0), _d3(c1), C.c_double(t0), C.c_double(t1), C.c_double(r), mat, flip, to_lights)
+
+    def add_plane(self, kind, a0, a1, b0, b1, k, mat, flip=0, to_lights=0):
+        return lib().orc_add_plane(self.h, kind, *[C.c_double(x) for x in (a0, a1, b0, b1, k)], mat, flip, to_lights)
+
+    def add_triangle_v(self, p, n, uv, mat, flip=0, to_lights=0):
+        return lib().orc_add_triangle_v(self.h, (C.c_double * 9)(*p), (C.c_double * 9)(*n), (C.c_double * 6)(*uv), mat, flip, to_lights)
+
+    def add_triangle_p(self, p, mat, flip=0, to_lights=0):
+        return lib().orc_add_triangle_p(self.h, (C.c_double * 9)(*p), mat, flip, to_lights)
+
+    def add_light_alias(self, prim_id):
+        return lib().orc_add_light_alias(self.h, prim_id)
+
+    def set_camera(self, pos, lookat, up, fov, aperture, focus, s0, s1):
+        lib().orc_set_camera(self.h, _d3(pos), _d3(lookat), _d3(up), *[C.c_double(x) for x in (fov, aperture, focus, s0, s1)])
+
+    def build_bvh(self):
+        lib().orc_build_bvh(self.h)
+
+    # ---- dumps
+    def tree_rows(self):
+        n = lib().orc_tree_rows(self.h, None, 0)
+        rows = np.zeros((n, TREE_ROW))
+        lib().orc_tree_rows(self.h, _p(rows, C.c_double), n)
+        return rows
+
+    def light_rows(self):
+        n = lib().orc_light_rows(self.h, None, 0)
+        rows = np.zeros((n, TREE_ROW))
+        lib().orc_light_rows(self.h, _p(rows, C.c_double), n)
+        return rows
+
+    def camera_fields(self):
+        out = np.zeros(24)
+        lib().orc_camera_fields(self.h, _p(out, C.c_double))
+        return out
+
+    def entry_prim_ids(self):
+        n = lib().orc_entry_prim_ids(self.h, None, 0)
+        out = np.zeros(n, dtype=np.int32)
+        lib().orc_entry_prim_ids(self.h, _p(out, C.c_int32), n)
+        return out
+
+    def export(self):
+        """Flattened scene as a dict of numpy arrays in the rt_scene_desc layout (include/rtcore.h)."""
+        c = np.zeros(8, dtype=np.int32)
+        lib().orc_export_counts(self.h, _p(c, C.c_int32))
+        nn, npr, nm, nt, nl, nr, nb = [int(x) for x in c[:7]]
+        d = dict(
+            node_bbox=np.zeros((nn, 6)), node_child=np.zeros((nn, 2), np.int32), roots=np.zeros(nr, np.int32),
+            prim_kind=np.zeros(npr, np.int32), prim_flags=np.zeros(npr, np.int32), prim_mat=np.zeros(npr, np.int32),
+            prim_data=np.zeros((npr, PRIM_STRIDE)),
+            mat_kind=np.zeros(nm, np.int32), mat_tex=np.zeros(nm, np.int32), mat_data=np.zeros((nm, MAT_STRIDE)),
+            tex_kind=np.zeros(nt, np.int32), tex_data=np.zeros((nt, TEX_STRIDE)), tex_pixels=np.zeros(max(nb, 1), np.uint8),
+            light_kind=np.zeros(nl, np.int32), light_flags=np.zeros(nl, np.int32), light_mat=np.zeros(nl, np.int32),
+            light_data=np.zeros((nl, PRIM_STRIDE)), camera=np.zeros(24),
+        )
+        I, D = C.c_int32, C.c_double
+        lib().orc_export(self.h, _p(d["node_bbox"], D), _p(d["node_child"], I), _p(d["roots"], I),
+                         _p(d["prim_kind"], I), _p(d["prim_flags"], I), _p(d["prim_mat"], I), _p(d["prim_data"], D),
+                         _p(d["mat_kind"], I), _p(d["mat_tex"], I), _p(d["mat_data"], D),
+                         _p(d["tex_kind"], I), _p(d["tex_data"], D), _p(d["tex_pixels"], C.c_uint8),
+                         _p(d["light_kind"], I), _p(d["light_flags"], I), _p(d["light_mat"], I), _p(d["light_data"], D),
+                         _p(d["camera"], D))
+        d["n_pixel_bytes"] = nb
+        d["width"], d["height"] = self.width, self.height
+        return d
+
+    # ---- hot path
+    def first_hit(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        n = len(rays)
+        out = dict(entry=np.zeros(n, np.int32), prim=np.zeros(n, np.int32), t=np.zeros(n), nbox=np.zeros(n, np.int32),
+                   nleaf=np.zeros(n, np.int32), front=np.zeros(n, np.int32), hash=np.zeros(n, np.uint64), rec=np.zeros((n, 9)))
+        lib().orc_first_hit(self.h, n, _p(rays, C.c_double), _p(out["entry"], C.c_int32), _p(out["prim"], C.c_int32),
+                            _p(out["t"], C.c_double), _p(out["nbox"], C.c_int32), _p(out["nleaf"], C.c_int32),
+                            _p(out["front"], C.c_int32), _p(out["hash"], C.c_uint64), _p(out["rec"], C.c_double))
+        return out
+
+    def primary_rays(self, side):
+        out = np.zeros((side * side, 7))
+        lib().orc_primary_rays(self.h, side, _p(out, C.c_double))
+        return out
+
+    def render(self, spp_begin, spp_end, max_depth, rng_mode=RNG_COUNTER, seed=0, n_threads=1, want_rgb=True):
+        w, h = self.width, self.height
+        total = np.zeros((h, w, 3))
+        rgb = np.zeros((h, w, 3), np.uint8)
+        counters = np.zeros(4, np.uint64)
+        lib().orc_render(self.h, spp_begin, spp_end, max_depth, rng_mode, C.c_uint64(seed), n_threads,
+                         _p(total, C.c_double), _p(rgb, C.c_uint8) if want_rgb else None, _p(counters, C.c_uint64))
+        return total, rgb, counters
+
+
+def resolve(total, spp):
+    total = np.ascontiguousarray(total, dtype=np.float64)
+    rgb = np.zeros(total.shape, np.uint8)
+    lib().orc_resolve(_p(total, C.c_double), total.size // 3, spp, _p(rgb, C.c_uint8))
+    return rgb
+
+
+def glibc_rand(seed, n):
+    out = np.zeros(n, np.int32)
+    lib().orc_glibc_rand_fill(seed, n, _p(out, C.c_int32))
+    return out
+
+
+def counter_rand(seed, pixel, sample, n):
+    out = np.zeros(n, np.uint32)
+    lib().orc_counter_rand_fill(C.c_uint64(seed), pixel, sample, n, _p(out, C.c_uint32))
+    return out
+
+
+def unit_aabb(inp):
+    inp = np.ascontiguousarray(inp, dtype=np.float64)
+    n = inp.size // 14
+    out = np.zeros(n, np.int32)
+    lib().orc_unit_aabb(n, _p(inp, C.c_double), _p(out, C.c_int32))
+    return out
+
+
+def unit_prim(inp):
+    inp = np.ascontiguousarray(inp, dtype=np.float64)
+    n = inp.size // 9
+    out, pdfs = np.zeros(5 * n * 12), np.zeros(5 * n)
+    lib().orc_unit_prim(n, _p(inp, C.c_double), _p(out, C.c_double), _p(pdfs, C.c_double))
+    return out, pdfs
+
+
+def unit_mat(inp):
+    inp = np.ascontiguousarray(inp, dtype=np.float64)
+    n = inp.size // 13
+    out = np.zeros(6 * n * 12)
+    lib().orc_unit_mat(n, _p(inp, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def unit_cam(n):
+    out, fields = np.zeros(n * 9), np.zeros(24)
+    lib().orc_unit_cam(n, _p(out, C.c_double), _p(fields, C.c_double))
+    return out, fields
+
+
+# ---------------------------------------------------------------- OBJ -> oracle scene (test-side restatement of loader.hpp:68-171)
+def load_obj_into(scene, path):
+    """Parse the small fixture OBJ/MTL the way the reference loader consumes tinyobj's output:
+    float32 attributes promoted to double, fan triangulation, per-face phong material, missing-normal fallback
+    computed from the (possibly stale) scratch vertices (loader.hpp:104-110), emissive faces aliased into lights."""
+    f32 = lambda s: float(np.float32(float(s)))
+    base = os.path.dirname(path)
+    mats, cur = {}, None
+    order = []
+    for line in open(path):
+        t = line.split()
+        if t and t[0] == "mtllib":
+            for ml in open(os.path.join(base, t[1])):
+                m = ml.split()
+                if not m:
+                    continue
+                if m[0] == "newmtl":
+                    cur = dict(Kd=[0.0] * 3, Ks=[0.0] * 3, Ke=[0.0] * 3, Tr=[0.0] * 3, Ns=f32(1.0), Ni=f32(1.0))
+                    mats[m[1]] = cur
+                    order.append(m[1])
+                elif m[0] in ("Kd", "Ks", "Ke"):
+                    cur[m[0]] = [f32(x) for x in m[1:4]]
+                elif m[0] in ("Tf", "Kt"):
+                    cur["Tr"] = [f32(x) for x in m[1:4]]
+                elif m[0] == "Ns":
+                    cur["Ns"] = f32(m[1])
+                elif m[0] == "Ni":
+                    cur["Ni"] = f32(m[1])
+    mat_ids = {name: scene.mat_phong(mats[name]["Kd"], mats[name]["Ks"], mats[name]["Ke"], mats[name]["Tr"],
+                                     mats[name]["Ns"], mats[name]["Ni"], -1) for name in order}
+    V, VN, VT = [], [], []
+    scratch = [dict(p=[0.0] * 3, n=[0.0] * 3, uv=[0.0] * 2) for _ in range(3)]
+    cur_mat = None
+
+    def vsub(a, b):
+        return [a[i] - b[i] for i in range(3)]
+
+    def cross(a, b):
+        return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+    def norm(a):
+        l = np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+        if l == 0:
+            return [0.0, 0.0, 0.0]
+        inv = 1 / l
+        return [inv * a[0], inv * a[1], inv * a[2]]
+
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            V.append([f32(x) for x in t[1:4]])
+        elif t[0] == "vn":
+            VN.append([f32(x) for x in t[1:4]])
+        elif t[0] == "vt":
+            VT.append([f32(x) for x in t[1:3]])
+        elif t[0] == "usemtl":
+            cur_mat = t[1]
+        elif t[0] == "f":
+            idx = []
+            for tok in t[1:]:
+                parts = tok.split("/")
+                vi = int(parts[0]) - 1
+                ti = int(parts[1]) - 1 if len(parts) > 1 and parts[1] else -1
+                ni = int(parts[2]) - 1 if len(parts) > 2 and parts[2] else -1
+                idx.append((vi, ti, ni))
+            if len(idx) == 4:
+                # tinyobjloader 2.0 quad rule: split along the shorter diagonal, float32 arithmetic, ties -> [0,1,3],[1,2,3]
+                q = [np.array(V[i[0]], dtype=np.float32) for i in idx]
+                e02, e13 = q[2] - q[0], q[3] - q[1]
+                s02 = np.float32(e02[0] * e02[0] + e02[1] * e02[1]) + e02[2] * e02[2]
+                s13 = np.float32(e13[0] * e13[0] + e13[1] * e13[1]) + e13[2] * e13[2]
+                tris = [[idx[0], idx[1], idx[2]], [idx[0], idx[2], idx[3]]] if s02 < s13 else [[idx[0], idx[1], idx[3]], [idx[1], idx[2], idx[3]]]
+            else:
+                tris = [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+            for tri in tris:
+                for vid, (vi, ti, ni) in enumerate(tri):
+                    scratch[vid]["p"] = list(V[vi])
+                    if ni >= 0:
+                        scratch[vid]["n"] = list(VN[ni])
+                    else:
+                        e1 = vsub(scratch[1]["p"], scratch[0]["p"])
+                        e2 = vsub(scratch[2]["p"], scratch[0]["p"])
+                        scratch[vid]["n"] = norm(cross(e1, e2))
+                    scratch[vid]["uv"] = list(VT[ti]) if ti >= 0 else [0.0, 0.0]
+                p = scratch[0]["p"] + scratch[1]["p"] + scratch[2]["p"]
+                n = scratch[0]["n"] + scratch[1]["n"] + scratch[2]["n"]
+                uv = scratch[0]["uv"] + scratch[1]["uv"] + scratch[2]["uv"]
+                pid = scene.add_triangle_v(p, n, uv, mat_ids[cur_mat])
+                ke = mats[cur_mat]["Ke"]
+                if ke[0] > 0 or ke[1] != 0 or ke[2] != 0:
+                    scene.add_light_alias(pid)
+    return scene
+
+
+def obj_scene(path, width, height, seed):
+    s = Scene.new(width, height, seed)
+    load_obj_into(s, path)
+    s.set_camera((0, 1.6, 4.2), (0, 0.6, 0), (0, 1, 0), 40, 0, 1, 0, 1)
+    s.build_bvh()
+    return s
