@@ -1,0 +1,145 @@
+/* include/rtcore.h -- C ABI of the MI355X path-tracing core (librtcore.so).
+ *
+ * Drop-in boundary for ONE hot path of ccronix/raytracing: the per-pixel bounce loop
+ *   render_image pixel/sample loop   src/cpp/raytracing.cpp:96-123
+ *   trace()                          src/cpp/raytracing.cpp:30-70
+ *   group/bvh/aabb/primitive intersect  group.hpp:68-83, bvh.hpp:58-68, aabb.hpp:23-41,
+ *                                    primitive.hpp:29-56,103-130,176-319, polygon.hpp:90-124
+ *   material shading / pdf / emit    material.hpp:20-312, texture.hpp:21-133
+ *   light sampling                   group.hpp:104-119, primitive.hpp:258-274, polygon.hpp:140-167
+ *   camera::emit                     camera.hpp:62-68
+ * The reference has no FFI: its boundary is the C++ `scene` object handed to trace().  Host code
+ * (raytracing_amd/host, source-compatible with the reference's scene/object/material classes) flattens a
+ * built `scene` into the plain-C `rt_scene_desc` below and calls these entry points; see INTEGRATION.md.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative RT_E* code and never exits or throws;
+ * rt_last_error() gives the message of the calling thread's last failure.  Pointers named *_dev are device
+ * pointers on the current HIP device; all others are host pointers.  The library keeps no global state
+ * except the per-thread error string; a scene belongs to the device that was current at rt_scene_create.
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK          0
+#define RT_EINVAL     -1   /* bad argument / malformed scene description */
+#define RT_EHIP       -2   /* a HIP runtime call failed */
+#define RT_ENOMEM     -3
+#define RT_EUNSUPPORTED -4
+
+/* primitive kinds: the reference's leaf object classes */
+#define RT_PRIM_SPHERE   1  /* sphere   primitive.hpp:13-75    data: c[3], radius                       */
+#define RT_PRIM_MSPHERE  2  /* msphere  primitive.hpp:78-155   data: c0[3], c1[3], start, end, radius   */
+#define RT_PRIM_PLANEXY  3  /* planexy  primitive.hpp:158-206  data: x0,x1,y0,y1,k                      */
+#define RT_PRIM_PLANEXZ  4  /* planexz  primitive.hpp:209-275  data: x0,x1,z0,z1,k                      */
+#define RT_PRIM_PLANEYZ  5  /* planeyz  primitive.hpp:278-326  data: y0,y1,z0,z1,k                      */
+#define RT_PRIM_TRIANGLE 6  /* triangle polygon.hpp:23-183     data: p0[3], p0p1[3], p0p2[3], n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2] */
+#define RT_PRIM_STRIDE  24  /* doubles per primitive record */
+#define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` */
+
+/* material kinds (material.hpp) and the layout of their RT_MAT_STRIDE doubles */
+#define RT_MAT_LAMBERTIAN 1 /* tex = base_color                                  */
+#define RT_MAT_METAL      2 /* tex = base_color; d[0] = roughness (already <= 1) */
+#define RT_MAT_DIELECTRIC 3 /* d[0] = ior                                        */
+#define RT_MAT_EMISSIVE   4 /* tex = emission                                    */
+#define RT_MAT_PHONG      5 /* tex = diffuse_map or -1; d[1..3] Kd, d[4..6] Ks, d[7..9] Ke, d[10..12] Tr, d[13] Ns, d[14] Ni */
+#define RT_MAT_STRIDE    16
+
+/* texture kinds (texture.hpp) and the layout of their RT_TEX_STRIDE doubles */
+#define RT_TEX_CONSTANT 1   /* d[0..2] rgb                                                        */
+#define RT_TEX_CHECKER  2   /* d[0] even texture index, d[1] odd texture index                    */
+#define RT_TEX_IMAGE    3   /* d[0] width, d[1] height, d[2] channels, d[3] color_based, d[4] byte offset into tex_pixels */
+#define RT_TEX_STRIDE    8
+
+typedef struct rt_scene rt_scene;   /* opaque: a scene resident in HBM */
+
+/* A built scene, flattened.  Caller keeps ownership; rt_scene_create copies everything it needs.
+ * The BVH is the reference's own tree (bvh.hpp:22-56), node by node: child code c >= 0 is node c, c < 0 is
+ * primitive ~c.  `roots` lists scene.objects' children in order (one entry after scene::build_bvh, scene.hpp:46-51).
+ * Primitive ids are insertion order into the scene, before the builder permutes the array. */
+typedef struct rt_scene_desc {
+    int32_t n_nodes;  const double* node_bbox;   /* n_nodes x 6: min xyz, max xyz */
+                      const int32_t* node_child; /* n_nodes x 2: left, right      */
+    int32_t n_roots;  const int32_t* roots;
+    int32_t n_prims;  const int32_t* prim_kind; const int32_t* prim_flags; const int32_t* prim_mat;
+                      const double* prim_data;   /* n_prims x RT_PRIM_STRIDE */
+    int32_t n_mats;   const int32_t* mat_kind;  const int32_t* mat_tex; const double* mat_data; /* n_mats x RT_MAT_STRIDE */
+    int32_t n_tex;    const int32_t* tex_kind;  const double* tex_data;                          /* n_tex x RT_TEX_STRIDE  */
+    size_t n_pixel_bytes; const uint8_t* tex_pixels;  /* image texels, stb layout (row-major, interleaved channels) */
+    /* scene.lights (scene.hpp:16): separate object instances, same record layout as primitives */
+    int32_t n_lights; const int32_t* light_kind; const int32_t* light_flags; const int32_t* light_mat;
+                      const double* light_data;  /* n_lights x RT_PRIM_STRIDE */
+    /* camera after setup_camera (camera.hpp:46-60): position[3], left_bottom[3], horizontal[3], vertical[3],
+     * u[3], v[3], w[3], lens_radius, shutter_start, shutter_end */
+    double camera[24];
+} rt_scene_desc;
+
+/* precision / traversal mode of rt_render */
+#define RT_MODE_REFERENCE_FP64 0 /* fp64, no FMA contraction, the reference's tree in the reference's visit order */
+#define RT_MODE_FAST_FP32      1 /* fp32, same tree and visit order, FMA allowed; accumulation buffer is fp32    */
+
+#define RT_FLAG_ACCUMULATE 1     /* add this call's sample sums into accum_dev instead of overwriting it */
+#define RT_FLAG_EARLY_EXIT 2     /* stop a path as soon as its sample is known to be rejected (NaN/inf, raytracing.cpp:108-110).
+                                    Same image; fewer rays than the reference traces.  Off by default. */
+
+typedef struct rt_render_params {
+    int32_t width, height;       /* image size: pixel (j,i) -> sample position as raytracing.cpp:102-103 */
+    int32_t y_begin, y_end;      /* rows rendered by this call (tile split); 0, height for the whole frame */
+    int32_t spp_begin, spp_end;  /* global sample indices rendered by this call (spp split)  */
+    int32_t max_depth;           /* raytracing.cpp:90 */
+    int32_t mode;                /* RT_MODE_* */
+    int32_t flags;               /* RT_FLAG_* */
+    uint64_t seed;               /* key of the counter-based RNG: stream = f(seed, pixel, sample) */
+    void* stream;                /* hipStream_t, NULL = default stream */
+} rt_render_params;
+
+typedef struct rt_render_stats {
+    uint64_t rays;               /* trace() invocations that traversed the scene (raytracing.cpp:32-37) */
+    uint64_t rejected_samples;   /* samples zeroed by the NaN/inf test (raytracing.cpp:108-110) */
+    double kernel_ms;            /* HIP-event time of the render kernel on params.stream */
+} rt_render_stats;
+
+/* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit
+ * `const scene&` argument of trace() (raytracing.cpp:30). */
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out);
+int rt_scene_destroy(rt_scene* scene);
+
+/* Renders samples [spp_begin, spp_end) of rows [y_begin, y_end): per pixel the SUM over those samples of
+ * trace(emit(x, y)) with rejected samples zeroed -- the body of the k-loop at raytracing.cpp:101-113.
+ * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
+ * double for RT_MODE_REFERENCE_FP64, float for RT_MODE_FAST_FP32.  Asynchronous on params->stream unless
+ * `stats` is non-NULL, in which case it synchronises the stream and fills *stats. */
+int rt_render(rt_scene* scene, const rt_render_params* params, void* accum_dev, rt_render_stats* stats);
+
+/* mean, gamma 0.45, clamp, truncate to 8 bit: raytracing.cpp:115-121.  rgb_dev: n_pixels*3 bytes. */
+int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream);
+
+/* Parity / debug entry: closest hit of explicit rays (origin[3], direction[3], time; t_min 1e-3, t_max inf as
+ * ray.hpp:12-13) through scene.objects.intersect (group.hpp:68-83 -> bvh.hpp:58-68), fp64, reference visit order.
+ * Outputs (host, any may be NULL): primitive id or -1, t, frontward flag, number of box tests, number of leaf
+ * tests, FNV-1a hash of the visited pre-order entry indices.  Synchronous. */
+int rt_first_hit(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
+                 uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);
+
+/* Device-buffer helpers for hosts that do not otherwise touch HIP (the C++ driver). */
+int rt_buffer_alloc(size_t bytes, void** dev_out);
+int rt_buffer_free(void* dev);
+int rt_buffer_download(void* host_dst, const void* dev_src, size_t bytes);
+int rt_buffer_upload(void* dev_dst, const void* host_src, size_t bytes);
+
+/* n draws of the counter-based stream (seed, pixel, sample), computed on the device (test hook for the RNG) */
+int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host);
+
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""raytracing_amd -- MI355X-native path-tracing core behind the reference's scene interface.
+
+Python here is plumbing (ctypes over the C ABI in include/rtcore.h, used by tests and bench.py);
+the product is raytracing_amd/librtcore.so (hand-written HIP for gfx950) and the C++ host mirror in
+raytracing_amd/host/.
+"""
+from .rtcore import (  # noqa: F401
+    MODE_FAST_FP32, MODE_REFERENCE_FP64, FLAG_ACCUMULATE, FLAG_EARLY_EXIT,
+    DeviceBuffer, RtError, Scene, debug_rng, load_library, resolve,
+)

@@ -1,0 +1,702 @@
+// raytracing_amd/csrc/rt_device.h -- device-side scene layout, RNG, traversal, shading and kernels.
+//
+// Hand-written HIP for gfx950 (wave64).  Everything is templated on the scalar R:
+//   R = double : RT_MODE_REFERENCE_FP64, compiled with -ffp-contract=off (rt_kernels_fp64.hip); evaluation
+//                order follows the reference line by line so closest hits are bit-identical to its g++ build.
+//   R = float  : RT_MODE_FAST_FP32 (rt_kernels_fp32.hip), FMA contraction allowed.
+// Reference citations are paths under the reference's src/cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_algebra/vec3.hpp"
+#include "rtcore.h"
+
+namespace rt {
+
+// ------------------------------------------------------------------ math overloads
+__device__ inline float  rt_sin(float v) { return sinf(v); }
+__device__ inline double rt_sin(double v) { return sin(v); }
+__device__ inline float  rt_cos(float v) { return cosf(v); }
+__device__ inline double rt_cos(double v) { return cos(v); }
+__device__ inline float  rt_acos(float v) { return acosf(v); }
+__device__ inline double rt_acos(double v) { return acos(v); }
+__device__ inline float  rt_atan2(float a, float b) { return atan2f(a, b); }
+__device__ inline double rt_atan2(double a, double b) { return atan2(a, b); }
+__device__ inline float  rt_pow(float a, float b) { return powf(a, b); }
+__device__ inline double rt_pow(double a, double b) { return pow(a, b); }
+__device__ inline float  rt_abs(float v) { return fabsf(v); }
+__device__ inline double rt_abs(double v) { return fabs(v); }
+__device__ inline float  rt_min(float a, float b) { return fminf(a, b); }
+__device__ inline double rt_min(double a, double b) { return fmin(a, b); }
+__device__ inline bool rt_finite(float v) { return isfinite(v); }
+__device__ inline bool rt_finite(double v) { return isfinite(v); }
+
+template <typename R> struct consts;
+template <> struct consts<double> {
+    static constexpr double pi = 3.141592653589;   // util.hpp:13 (truncated on purpose)
+    static constexpr double eps = 1e-7;            // util.hpp:14
+    static constexpr double tmin = 1e-3;           // ray.hpp:12
+};
+template <> struct consts<float> {
+    static constexpr float pi = 3.141592653589f;
+    static constexpr float eps = 1e-7f;
+    static constexpr float tmin = 1e-3f;
+};
+template <typename R> __device__ inline R rt_inf() { return R(__builtin_huge_val()); }
+
+// ------------------------------------------------------------------ device scene layout (HBM; small scenes are staged into LDS)
+// Reference-order traversal program: the reference tree (bvh.hpp) written out in pre-order.  An entry is either a
+// bvh node (prim < 0: test the box, on a miss jump to `skip`) or a leaf reference (prim >= 0: intersect it).
+// Walking it front to back with one running t_max IS bvh::intersect's recursion (bvh.hpp:58-68): left subtree,
+// then right subtree with t_max shrunk; a span-1 node's leaf appears twice, as it is tested twice.
+template <typename R> struct alignas(8) Op {
+    R mn[3], mx[3];
+    int32_t skip;
+    int32_t prim;
+};
+// hot primitive record (intersection only).  g[]: sphere c,r | msphere c0,c1,start,end,r | plane a0,a1,b0,b1,k | triangle p0,e1,e2
+template <typename R> struct alignas(16) Prim {
+    R g[12];
+    int32_t kind, flags, mat, pad;
+};
+// cold triangle record (shading only): vertex normals and uvs
+template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
+template <typename R> struct Mat { int32_t kind, tex; R d[16]; };
+template <typename R> struct Tex { int32_t kind, a, b, ch, color_based; uint32_t offset; R rgb[3]; R pad; };
+template <typename R> struct Camera { vec3<R> pos, left_bottom, horizontal, vertical, u, v; R lens_radius, s0, s1; };
+
+template <typename R> struct Scene {
+    const Op<R>* ops; int32_t n_ops;
+    const Prim<R>* prims; int32_t n_prims;
+    const TriShade<R>* tris;          // n_prims entries or null when the scene has no triangles
+    const Mat<R>* mats;
+    const Tex<R>* texs;
+    const uint8_t* pixels;
+    const Prim<R>* lights; const TriShade<R>* light_tris; int32_t n_lights;
+    int32_t need_uv;                  // some material reads uv (image texture)
+    Camera<R> cam;
+};
+
+template <typename R> struct Ray { vec3<R> o, d; R time; };
+
+// ------------------------------------------------------------------ counter-based RNG
+// PCG32 XSH-RR over a state hashed from (seed, pixel, sample): nothing is stored between samples or launches,
+// so any (pixel, sample) can be rendered on any GPU in any order.  Bit-identical to oracle/rt_oracle.c.
+__host__ __device__ inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t s;
+    __host__ __device__ void seed(uint64_t seed, uint32_t pixel, uint32_t sample)
+    {
+        uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ULL * (1ULL + pixel));
+        s = mix64(h ^ (0xD1B54A32D192ED03ULL * (1ULL + sample)));
+    }
+    __host__ __device__ uint32_t next()
+    {
+        uint64_t old = s;
+        s = old * 6364136223846793005ULL + 1442695040888963407ULL;
+        uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27);
+        uint32_t rot = (uint32_t) (old >> 59);
+        return (xs >> rot) | (xs << ((32 - rot) & 31));
+    }
+};
+template <typename R> __device__ inline R uniform(Rng& g);
+template <> __device__ inline double uniform<double>(Rng& g) { return g.next() * (1.0 / 4294967296.0); }        // util.hpp:30-33
+template <> __device__ inline float uniform<float>(Rng& g) { return (g.next() >> 8) * (1.0f / 16777216.0f); }
+template <typename R> __device__ inline R uniform(Rng& g, R mn, R mx) { return mn + (mx - mn) * uniform<R>(g); } // util.hpp:36-39
+
+// Draw order inside these helpers is the reference's as compiled by g++ (constructor arguments evaluate right to
+// left); it is pinned by the golden fixtures through the oracle.
+template <typename R> __device__ inline vec3<R> random_sphere(Rng& g)          // util.hpp:60-70
+{
+    for (;;) {
+        R z = uniform<R>(g, R(-1), R(1)), y = uniform<R>(g, R(-1), R(1)), x = uniform<R>(g, R(-1), R(1));
+        vec3<R> p(x, y, z);
+        R l = length(p);
+        if (l * l >= R(1)) continue;
+        return normalize(p);
+    }
+}
+template <typename R> __device__ inline vec3<R> random_disk(Rng& g)            // util.hpp:85-95
+{
+    for (;;) {
+        R y = uniform<R>(g, R(-1), R(1)), x = uniform<R>(g, R(-1), R(1));
+        vec3<R> p(x, y, R(0));
+        R l = length(p);
+        if (l * l >= R(1)) continue;
+        return p;
+    }
+}
+template <typename R> __device__ inline vec3<R> random_cosine(Rng& g)          // util.hpp:98-107
+{
+    R r1 = uniform<R>(g), r2 = uniform<R>(g);
+    R z = rt_sqrt(R(1) - r2);
+    R phi = R(2) * consts<R>::pi * r1;
+    R x = rt_cos(phi) * rt_sqrt(r2);
+    R y = rt_sin(phi) * rt_sqrt(r2);
+    return vec3<R>(x, y, z);
+}
+template <typename R> __device__ inline vec3<R> reflect(const vec3<R>& in, const vec3<R>& n) { return in - (R(2) * dot(in, n)) * n; } // util.hpp:154-157
+template <typename R> __device__ inline vec3<R> refract(const vec3<R>& in, const vec3<R>& n, R ratio)                                  // util.hpp:160-166
+{
+    R cos_theta = rt_min(-dot(in, n), R(1));
+    vec3<R> perp = ratio * (in + cos_theta * n);
+    R pl = length(perp);
+    vec3<R> par = (-rt_sqrt(rt_abs(R(1) - pl * pl))) * n;
+    return perp + par;
+}
+
+// ------------------------------------------------------------------ intersection
+template <typename R> __device__ inline bool box_hit(const Op<R>& b, const Ray<R>& r, R t_min, R t_max)   // aabb.hpp:23-41
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        R inv = R(1) / r.d[i];
+        R t0 = (b.mn[i] - r.o[i]) * inv;
+        R t1 = (b.mx[i] - r.o[i]) * inv;
+        if (inv < R(0)) { R s = t0; t0 = t1; t1 = s; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+template <typename R> __device__ inline vec3<R> msphere_center(const Prim<R>& p, R time)                  // primitive.hpp:98-101
+{
+    vec3<R> c0(p.g[0], p.g[1], p.g[2]), c1(p.g[3], p.g[4], p.g[5]);
+    return c0 + ((time - p.g[6]) / (p.g[7] - p.g[6])) * (c1 - c0);
+}
+
+template <typename R> __device__ inline bool sphere_t(const vec3<R>& center, R radius, const Ray<R>& r, R t_min, R t_max, R& t)
+{                                                                                                         // primitive.hpp:31-48
+    vec3<R> oc = r.o - center;
+    R a = dot(r.d, r.d);
+    R b = R(2) * dot(oc, r.d);
+    R c = dot(oc, oc) - radius * radius;
+    R disc = b * b - R(4) * a * c;
+    if (disc < R(0)) return false;
+    R sq = rt_sqrt(disc);
+    R root = (-b - sq) / (a * R(2));
+    if (root < t_min || root > t_max) {
+        root = (-b + sq) / (a * R(2));
+        if (root < t_min || root > t_max) return false;
+    }
+    t = root;
+    return true;
+}
+
+__device__ inline void plane_axes(int kind, int& ax, int& bx, int& kx)
+{
+    if (kind == RT_PRIM_PLANEXY) { ax = 0; bx = 1; kx = 2; }
+    else if (kind == RT_PRIM_PLANEXZ) { ax = 0; bx = 2; kx = 1; }
+    else { ax = 1; bx = 2; kx = 0; }
+}
+
+template <typename R> __device__ inline bool plane_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t, R& a, R& b)
+{                                                                                                         // primitive.hpp:176-187 / 227-238 / 296-307
+    int ax, bx, kx;
+    plane_axes(p.kind, ax, bx, kx);
+    R tt = (p.g[4] - r.o[kx]) / r.d[kx];
+    if (tt < t_min || tt > t_max) return false;
+    a = r.o[ax] + tt * r.d[ax];
+    b = r.o[bx] + tt * r.d[bx];
+    if (a < p.g[0] || a > p.g[1] || b < p.g[2] || b > p.g[3]) return false;
+    t = tt;
+    return true;
+}
+
+template <typename R> __device__ inline bool tri_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t, R& u, R& v)
+{                                                                                                         // polygon.hpp:93-115
+    vec3<R> p0(p.g[0], p.g[1], p.g[2]), e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
+    vec3<R> q = cross(r.d, e2);
+    R a = dot(e1, q);
+    if (rt_abs(a) < consts<R>::eps) return false;
+    R f = R(1) / a;
+    vec3<R> s = r.o - p0;
+    u = f * dot(s, q);
+    if (u < R(0)) return false;
+    vec3<R> k = cross(s, e1);
+    v = f * dot(r.d, k);
+    if (v < R(0) || u + v > R(1)) return false;
+    R tt = f * dot(e2, k);
+    if (tt < t_min || tt > t_max) return false;
+    t = tt;
+    return true;
+}
+
+template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t)
+{
+    R a, b;
+    switch (p.kind) {
+    case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
+    case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
+    case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
+    default: return plane_t(p, r, t_min, t_max, t, a, b);
+    }
+}
+
+// hit record (intersection.hpp:13-27)
+template <typename R> struct Hit {
+    vec3<R> pos, normal;
+    R u, v, t;
+    int32_t mat;
+    bool front;
+};
+
+template <typename R> __device__ inline void set_face_normal(Hit<R>& h, const Ray<R>& r, const vec3<R>& n)  // intersection.hpp:22-26
+{
+    h.front = dot(r.d, n) < R(0);
+    h.normal = h.front ? n : -n;
+}
+
+// Completes the record of a hit already known to lie at t on primitive p: the statements after the range test in
+// each intersect() (primitive.hpp:49-55, 123-129, 189-198; polygon.hpp:117-123; flip transform.hpp:134).
+template <typename R> __device__ inline void fill_record(const Prim<R>& p, const TriShade<R>* tris, int prim_index, const Ray<R>& r, R t,
+                                                         bool need_uv, Hit<R>& h)
+{
+    h.t = t;
+    h.mat = p.mat;
+    h.u = h.v = R(0);
+    switch (p.kind) {
+    case RT_PRIM_SPHERE:
+    case RT_PRIM_MSPHERE: {
+        vec3<R> c = p.kind == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);
+        R radius = p.kind == RT_PRIM_SPHERE ? p.g[3] : p.g[8];
+        h.pos = r.o + t * r.d;
+        vec3<R> n = (h.pos - c) / radius;
+        set_face_normal(h, r, n);
+        if (need_uv) {                                                      // primitive.hpp:67-74
+            R theta = rt_acos(-n.y);
+            R phi = rt_atan2(-n.z, n.x) + consts<R>::pi;
+            h.u = phi / (R(2) * consts<R>::pi);
+            h.v = theta / consts<R>::pi;
+        }
+        break;
+    }
+    case RT_PRIM_TRIANGLE: {
+        R tt, u, v;
+        tri_t(p, r, -rt_inf<R>(), rt_inf<R>(), tt, u, v);                   // same arithmetic as the accepted test
+        h.pos = r.o + t * r.d;
+        const TriShade<R>& s = tris[prim_index];
+        R w = R(1) - u - v;
+        h.u = (u * s.uv[2] + v * s.uv[4]) + w * s.uv[0];                    // polygon.hpp:174-177
+        h.v = (u * s.uv[3] + v * s.uv[5]) + w * s.uv[1];
+        vec3<R> n0(s.n[0], s.n[1], s.n[2]), n1(s.n[3], s.n[4], s.n[5]), n2(s.n[6], s.n[7], s.n[8]);
+        vec3<R> n = (u * n1 + v * n2) + w * n0;                             // polygon.hpp:179-182 (not re-normalised)
+        set_face_normal(h, r, n);
+        break;
+    }
+    default: {
+        int ax, bx, kx;
+        plane_axes(p.kind, ax, bx, kx);
+        R a = r.o[ax] + t * r.d[ax];
+        R b = r.o[bx] + t * r.d[bx];
+        h.u = (a - p.g[0]) / (p.g[1] - p.g[0]);
+        h.v = (b - p.g[2]) / (p.g[3] - p.g[2]);
+        vec3<R> n(kx == 0 ? R(1) : R(0), kx == 1 ? R(1) : R(0), kx == 2 ? R(1) : R(0));
+        set_face_normal(h, r, n);
+        h.pos = r.o + t * r.d;
+        break;
+    }
+    }
+    if (p.flags & RT_PRIM_FLAG_FLIP) h.front = !h.front;
+}
+
+struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; };
+
+// scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
+template <typename R, bool kStats>
+__device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const Ray<R>& r,
+                                  R& t_hit, VisitStats* st)
+{
+    R closest = rt_inf<R>();
+    const R t_min = consts<R>::tmin;
+    int hit = -1;
+    int i = 0;
+    while (i < n_ops) {
+        const Op<R> op = ops[i];
+        if (kStats) st->hash = (st->hash ^ (uint64_t) (uint32_t) i) * 0x100000001B3ULL;
+        if (op.prim < 0) {
+            if (kStats) st->n_box++;
+            i = box_hit(op, r, t_min, closest) ? i + 1 : op.skip;
+        }
+        else {
+            if (kStats) st->n_leaf++;
+            R t;
+            if (prim_t(prims[op.prim], r, t_min, closest, t)) { closest = t; hit = op.prim; }
+            i++;
+        }
+    }
+    t_hit = closest;
+    return hit;
+}
+
+// ------------------------------------------------------------------ textures and materials
+template <typename R> __device__ inline vec3<R> tex_color(const Scene<R>& sc, int ti, const vec3<R>& pos, R u, R v)
+{
+    for (int level = 0; level < 8; level++) {
+        const Tex<R>& t = sc.texs[ti];
+        if (t.kind == RT_TEX_CONSTANT) return vec3<R>(t.rgb[0], t.rgb[1], t.rgb[2]);        // texture.hpp:32-35
+        if (t.kind == RT_TEX_CHECKER) {                                                     // texture.hpp:65-74
+            R sine = rt_sin(R(10) * pos.x) * rt_sin(R(10) * pos.y) * rt_sin(R(10) * pos.z);
+            ti = sine < R(0) ? t.a : t.b;
+            continue;
+        }
+        if (t.kind == RT_TEX_IMAGE) {                                                       // texture.hpp:95-124
+            if (t.a <= 0) return vec3<R>(R(0), R(1), R(1));
+            R uu = u < R(0) ? R(0) : (u > R(1) ? R(1) : u);
+            R vv = R(1) - (v < R(0) ? R(0) : (v > R(1) ? R(1) : v));
+            int x = (int) (uu * t.a), y = (int) (vv * t.b);
+            if (x >= t.a) x = t.a - 1;
+            if (y >= t.b) y = t.b - 1;
+            const uint8_t* b = sc.pixels + t.offset + ((size_t) y * t.a * t.ch + (size_t) x * t.ch);
+            const R scale = R(1) / R(255);
+            vec3<R> c = scale * vec3<R>(R(b[0]), R(b[1]), R(b[2]));
+            if (t.color_based) return vec3<R>(rt_pow(c.x, R(2.2)), rt_pow(c.y, R(2.2)), rt_pow(c.z, R(2.2)));
+            return c;
+        }
+        break;
+    }
+    return vec3<R>();
+}
+
+template <typename R> __device__ inline bool nz3(const R* k) { return k[0] > R(0) || k[1] != R(0) || k[2] != R(0); }   // material.hpp:298-302
+
+template <typename R> __device__ inline R reflectance(R cos_theta, R ior)                                              // material.hpp:128-133
+{
+    R r = (R(1) - ior) / (R(1) + ior);
+    r = r * r;
+    return r + (R(1) - r) * rt_pow(R(1) - cos_theta, R(5));
+}
+
+template <typename R> __device__ inline vec3<R> glass_dir(Rng& g, const Ray<R>& wi, const Hit<R>& h, R ior)            // material.hpp:109-122
+{
+    R ratio = h.front ? (R(1) / ior) : ior;
+    vec3<R> next = normalize(wi.d);
+    R cos_theta = rt_min(dot(-next, h.normal), R(1));
+    R sin_theta = rt_sqrt(R(1) - cos_theta * cos_theta);
+    bool not_refract = ratio * sin_theta > R(1);
+    if (not_refract || reflectance(cos_theta, ratio) > uniform<R>(g)) return reflect(next, h.normal);
+    return refract(next, h.normal, ratio);
+}
+
+template <typename R> __device__ inline vec3<R> cosine_sample(Rng& g, const vec3<R>& normal)                           // material.hpp:43-52
+{
+    vec3<R> rc = random_cosine<R>(g);
+    vec3<R> a2 = normalize(normal);
+    vec3<R> x = (rt_abs(a2.x) > R(0.9)) ? vec3<R>(R(0), R(1), R(0)) : vec3<R>(R(1), R(0), R(0));
+    vec3<R> a1 = normalize(cross(a2, x));
+    vec3<R> a0 = cross(a2, a1);
+    return (rc.x * a0 + rc.y * a1) + rc.z * a2;
+}
+
+template <typename R> __device__ inline vec3<R> mat_emit(const Scene<R>& sc, const Mat<R>& m, const Hit<R>& h)
+{
+    if (m.kind == RT_MAT_EMISSIVE) return h.front ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();                 // material.hpp:146-154
+    if (m.kind == RT_MAT_PHONG) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
+    return vec3<R>();
+}
+
+// material::shading.  wo keeps its default (origin 0, direction 0, time 0: `ray wo;` raytracing.cpp:41) when the
+// material does not set it (phong's specular and diffuse branches).
+template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h,
+                                                         Ray<R>& wo, vec3<R>& att, bool& spec)
+{
+    switch (m.kind) {
+    case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
+        spec = false;
+        wo.o = h.pos; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
+        att = tex_color(sc, m.tex, h.pos, h.u, h.v);
+        return true;
+    case RT_MAT_METAL: {                                                                    // material.hpp:74-82
+        vec3<R> next = reflect(normalize(wi.d), h.normal);
+        vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
+        wo.o = h.pos; wo.d = next + fuzz; wo.time = wi.time;
+        att = tex_color(sc, m.tex, h.pos, h.u, h.v);
+        spec = true;
+        return true;
+    }
+    case RT_MAT_DIELECTRIC:                                                                 // material.hpp:105-125
+        spec = true;
+        att = vec3<R>(R(1), R(1), R(1));
+        wo.o = h.pos; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
+        return true;
+    case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
+        if (nz3(m.d + 7)) return false;
+        vec3<R> base = (m.tex >= 0) ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>(m.d[1], m.d[2], m.d[3]);
+        if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
+            att = vec3<R>(m.d[4], m.d[5], m.d[6]);
+            spec = true;
+            return true;
+        }
+        if (nz3(m.d + 10)) {
+            spec = true;
+            att = vec3<R>(m.d[10], m.d[11], m.d[12]);
+            wo.o = h.pos; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
+            return true;
+        }
+        spec = false;
+        att = base;
+        return true;
+    }
+    default: return false;                                                                  // emissive material.hpp:156-159
+    }
+}
+
+template <typename R> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)
+{
+    switch (m.kind) {
+    case RT_MAT_LAMBERTIAN: {                                                               // material.hpp:37-41
+        R c = dot(h.normal, normalize(wo.d));
+        return c > R(0) ? c / consts<R>::pi : R(0);
+    }
+    case RT_MAT_METAL: {                                                                    // material.hpp:84-88
+        R c = dot(h.normal, normalize(wo.d));
+        return c > consts<R>::eps ? R(1) : R(0);
+    }
+    case RT_MAT_PHONG: {                                                                    // material.hpp:257-266
+        R c = dot(h.normal, normalize(wo.d));
+        if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);
+        return c > R(0) ? c / consts<R>::pi : R(0);
+    }
+    default: return R(0);                                                                   // material.hpp:14
+    }
+}
+
+// ------------------------------------------------------------------ lights (group.hpp:104-119 over planexz / triangle)
+template <typename R> __device__ inline R light_pdf(const Scene<R>& sc, int li, const vec3<R>& origin, const vec3<R>& value)
+{
+    const Prim<R>& p = sc.lights[li];
+    Ray<R> r; r.o = origin; r.d = value; r.time = R(0);                                     // ray(origin, value): time 0, t_min 1e-3, t_max inf
+    R t, a, b;
+    vec3<R> normal;
+    R area;
+    if (p.kind == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:258-269
+        if (!plane_t(p, r, consts<R>::tmin, rt_inf<R>(), t, a, b)) return R(0);
+        vec3<R> n(R(0), R(1), R(0));
+        normal = dot(r.d, n) < R(0) ? n : -n;
+        area = (p.g[1] - p.g[0]) * (p.g[3] - p.g[2]);
+    }
+    else if (p.kind == RT_PRIM_TRIANGLE) {                                                  // polygon.hpp:140-151
+        R u, v;
+        if (!tri_t(p, r, consts<R>::tmin, rt_inf<R>(), t, u, v)) return R(0);
+        const TriShade<R>& s = sc.light_tris[li];
+        R w = R(1) - u - v;
+        vec3<R> n0(s.n[0], s.n[1], s.n[2]), n1(s.n[3], s.n[4], s.n[5]), n2(s.n[6], s.n[7], s.n[8]);
+        vec3<R> n = (u * n1 + v * n2) + w * n0;
+        normal = dot(r.d, n) < R(0) ? n : -n;
+        vec3<R> e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
+        area = length(cross(e1, e2)) / R(2);
+    }
+    else return R(0);                                                                       // object.hpp:16
+    R len = length(value);
+    R dist2 = t * t * len * len;
+    R cosine = rt_abs(dot(value, normal) / len);
+    return dist2 / (cosine * area);
+}
+
+template <typename R> __device__ inline vec3<R> light_rand(const Scene<R>& sc, Rng& g, const vec3<R>& origin)
+{
+    int idx = (int) uniform<R>(g, R(0), R(sc.n_lights));                                    // group.hpp:117, util.hpp:42-45
+    if (idx >= sc.n_lights) idx = sc.n_lights - 1;                                          // fp32 only: guards u*n rounding up to n
+    const Prim<R>& p = sc.lights[idx];
+    if (p.kind == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:270-274
+        R z = uniform<R>(g, p.g[2], p.g[3]);
+        R x = uniform<R>(g, p.g[0], p.g[1]);
+        return vec3<R>(x, p.g[4], z) - origin;
+    }
+    if (p.kind == RT_PRIM_TRIANGLE) {                                                       // polygon.hpp:153-167
+        vec3<R> p0(p.g[0], p.g[1], p.g[2]), e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
+        R u = uniform<R>(g), v = uniform<R>(g);
+        vec3<R> q = (u + v > R(1)) ? (p0 + (R(1) - u) * e1) + (R(1) - v) * e2 : (p0 + u * e1) + v * e2;
+        return q - origin;
+    }
+    return vec3<R>(R(1), R(0), R(0));                                                       // object.hpp:17
+}
+
+template <typename R> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value)
+{
+    R weight = R(1) / R(sc.n_lights);
+    R avg = R(0);
+    for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf(sc, i, origin, value);
+    return avg;
+}
+
+// ------------------------------------------------------------------ camera (camera.hpp:62-68)
+template <typename R> __device__ inline Ray<R> camera_emit(const Camera<R>& c, Rng& g, R x, R y)
+{
+    vec3<R> defocus = c.lens_radius * random_disk<R>(g);
+    vec3<R> offset = defocus.x * c.u + defocus.y * c.v;
+    Ray<R> r;
+    r.d = (((c.left_bottom + x * c.horizontal) + y * c.vertical) - c.pos) - offset;
+    r.o = c.pos + offset;
+    r.time = uniform<R>(g, c.s0, c.s1);
+    return r;
+}
+
+// ------------------------------------------------------------------ launch parameters shared with the host side
+struct RenderArgs {
+    int32_t width, height, y_begin, y_end, spp_begin, spp_end, max_depth, flags;
+    uint64_t seed;
+    uint32_t lds_ops_bytes, lds_prims_bytes;   // 0: read the traversal program from global memory
+};
+
+// ------------------------------------------------------------------ render kernel
+// One lane owns one pixel and walks its samples [spp_begin, spp_end).  The bounce loop is flattened: every
+// iteration each live lane extends its path by ONE segment; a lane whose path ended regenerates the next camera
+// sample in place (path regeneration), so a wave only idles at the very end of its pixels' sample ranges instead
+// of after every sample.  Waves are 8x8 pixel tiles; a 256-thread workgroup is a 16x16 tile.
+//
+// Iterative form of trace() (raytracing.cpp:30-70): L = sum_i beta_i * emission_i with
+// beta_{i+1} = beta_i (*) (1/pdf_i) * (mat_pdf_i * attenuation_i).  The reference's recursion multiplies the same
+// factors on the way back up, so a non-finite 1/pdf or weight anywhere poisons the whole sample, even when the
+// path later misses (0 * inf); `poisoned` carries that.
+template <typename R, bool kLds>
+__global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Op<R>* ops = sc.ops;
+    const Prim<R>* prims = sc.prims;
+    if (kLds) {
+        // stage the whole traversal program into LDS: 16-byte copies, all 256 threads
+        const uint4* src0 = reinterpret_cast<const uint4*>(sc.ops);
+        uint4* dst0 = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < a.lds_ops_bytes / 16; i += blockDim.x) dst0[i] = src0[i];
+        const uint4* src1 = reinterpret_cast<const uint4*>(sc.prims);
+        uint4* dst1 = reinterpret_cast<uint4*>(smem + a.lds_ops_bytes);
+        for (uint32_t i = threadIdx.x; i < a.lds_prims_bytes / 16; i += blockDim.x) dst1[i] = src1[i];
+        __syncthreads();
+        ops = reinterpret_cast<const Op<R>*>(smem);
+        prims = reinterpret_cast<const Prim<R>*>(smem + a.lds_ops_bytes);
+    }
+
+    const int tiles_x = (a.width + 15) >> 4;
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int i = a.y_begin + tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_image = j < a.width && i < a.y_end;
+
+    unsigned long long n_rays = 0, n_rejected = 0;
+    vec3<R> sum;
+
+    if (in_image) {
+        const uint32_t pixel = (uint32_t) (i * a.width + j);
+        int k = a.spp_begin;
+        bool alive = false, poisoned = false;
+        int depth = 0;
+        Rng g; g.s = 0;
+        Ray<R> ray;
+        vec3<R> beta, L;
+
+        for (;;) {
+            if (!alive) {
+                if (k >= a.spp_end) break;
+                g.seed(a.seed, pixel, (uint32_t) k);
+                k++;
+                R x = (R(j) + uniform<R>(g)) / R(a.width - 1);                             // raytracing.cpp:102-103
+                R y = (R(i) + uniform<R>(g)) / R(a.height - 1);
+                ray = camera_emit(sc.cam, g, x, y);
+                beta = vec3<R>(R(1), R(1), R(1));
+                L = vec3<R>();
+                depth = a.max_depth;
+                poisoned = false;
+                alive = depth > 0;
+                if (!alive) continue;
+            }
+
+            // ---- one path segment: trace() body for the current depth
+            n_rays++;
+            R t;
+            int prim = closest_hit<R, false>(ops, sc.n_ops, prims, ray, t, nullptr);
+            bool done = true;
+            if (prim >= 0) {
+                Hit<R> h;
+                fill_record(prims[prim], sc.tris, prim, ray, t, sc.need_uv != 0, h);
+                const Mat<R>& m = sc.mats[h.mat];
+                vec3<R> emission = mat_emit(sc, m, h);
+                Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
+                vec3<R> att;
+                bool spec = false;
+                L += beta * emission;
+                if (mat_shading(sc, g, m, ray, h, wo, att, spec)) {
+                    R pdf, mpdf;
+                    if (spec) {                                                             // raytracing.cpp:51-54
+                        mpdf = mat_pdf(g, m, h, wo);
+                        pdf = mpdf;
+                    }
+                    else {                                                                  // raytracing.cpp:55-61
+                        if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                        mpdf = mat_pdf(g, m, h, wo);
+                        pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                    }
+                    R inv = R(1) / pdf;                                                     // raytracing.cpp:69, vec3.hpp:121-123
+                    vec3<R> w = mpdf * att;
+                    if (!rt_finite(inv) || !rt_finite(w.x) || !rt_finite(w.y) || !rt_finite(w.z)) poisoned = true;
+                    beta = beta * (inv * w);
+                    ray = wo;
+                    depth--;
+                    done = depth <= 0;
+                    if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
+                }
+            }
+            if (done) {
+                alive = false;
+                bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
+                if (bad) n_rejected++;
+                else sum += L;
+            }
+        }
+
+        R* out = accum + (size_t) pixel * 3;
+        if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sum.x; out[1] += sum.y; out[2] += sum.z; }
+        else { out[0] = sum.x; out[1] = sum.y; out[2] = sum.z; }
+    }
+
+    // wave-level reduction of the counters, one atomic pair per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_rays += __shfl_down(n_rays, off, 64);
+        n_rejected += __shfl_down(n_rejected, off, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_rays);
+        if (n_rejected) atomicAdd(&counters[1], n_rejected);
+    }
+}
+
+// ------------------------------------------------------------------ parity kernel: explicit rays, with visit statistics
+template <typename R>
+__global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const double* __restrict__ rays, int n, int32_t* prim, double* t_out,
+                                                        int32_t* front, uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double* p = rays + (size_t) idx * 7;
+    Ray<R> r;
+    r.o = vec3<R>(R(p[0]), R(p[1]), R(p[2]));
+    r.d = vec3<R>(R(p[3]), R(p[4]), R(p[5]));
+    r.time = R(p[6]);
+    VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL;
+    R t;
+    int hit = closest_hit<R, true>(sc.ops, sc.n_ops, sc.prims, r, t, &st);
+    prim[idx] = hit;
+    t_out[idx] = hit >= 0 ? (double) t : 0.0;
+    int f = -1;
+    if (hit >= 0) {
+        Hit<R> h;
+        fill_record(sc.prims[hit], sc.tris, hit, r, t, false, h);
+        f = h.front ? 1 : 0;
+    }
+    front[idx] = f;
+    n_box[idx] = st.n_box; n_leaf[idx] = st.n_leaf; hash[idx] = st.hash;
+}
+
+}  // namespace rt

@@ -1,0 +1,5 @@
+// fp64 reference-order kernels.  Build with -ffp-contract=off: no FMA, so +,-,*,/ and sqrt round exactly as in
+// the reference's g++ -O3 x86-64 build ("fp64 vs fp32").
+#define RT_REAL double
+#define RT_WITH_FIRST_HIT 1
+#include "rt_kernels.inl"

@@ -1,0 +1,12 @@
+// raytracing_amd/csrc/rt_launch.h -- host-callable launchers, one overload set per precision.
+// rt_kernels_fp64.hip is compiled with -ffp-contract=off (bit-exact reference arithmetic),
+// rt_kernels_fp32.hip with the default contraction.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+hipError_t launch_render(const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, hipStream_t s);
+hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* accum, unsigned long long* counters, hipStream_t s);
+hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,
+                            uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash, hipStream_t s);
+}  // namespace rt

@@ -1,0 +1,408 @@
+// raytracing_amd/csrc/rtcore.hip -- C ABI (include/rtcore.h): scene upload, launches, resolve.
+//
+// HBM layout built here from rt_scene_desc (all arrays are flat, index-linked; no pointers inside records):
+//   ops   : the reference BVH in pre-order, one record per bvh node / leaf reference (Op<R>, 32 B fp32 / 56 B fp64)
+//   prims : hot intersection records by primitive id (Prim<R>, 64 B fp32 / 112 B fp64)
+//   tris  : cold per-triangle shading records (normals + uvs), only when the scene has triangles
+//   mats, texs, pixels, lights, light_tris
+// Both precisions are resident so one scene serves the parity entry points and the fast renderer.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_launch.h"
+#include "rtcore.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(RT_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+template <typename R> struct DeviceScene {
+    rt::Scene<R> view{};
+    std::vector<void*> owned;
+    uint32_t ops_bytes = 0, prims_bytes = 0;   // padded to 16
+};
+
+template <typename T> int upload(std::vector<void*>& owned, const std::vector<T>& host, const T** dev, size_t pad_to = 16)
+{
+    size_t bytes = host.size() * sizeof(T);
+    size_t padded = ((bytes + pad_to - 1) / pad_to) * pad_to;
+    if (padded == 0) padded = pad_to;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, padded));
+    owned.push_back(p);
+    HIP_TRY(hipMemset(p, 0, padded));
+    if (bytes) HIP_TRY(hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+    *dev = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+inline float down(double v) { float f = (float) v; return (double) f > v ? std::nextafterf(f, -INFINITY) : f; }
+inline float up(double v) { float f = (float) v; return (double) f < v ? std::nextafterf(f, INFINITY) : f; }
+template <typename R> R box_lo(double v);
+template <typename R> R box_hi(double v);
+template <> double box_lo<double>(double v) { return v; }
+template <> double box_hi<double>(double v) { return v; }
+template <> float box_lo<float>(double v) { return down(v); }   // fp32 boxes contain the fp64 boxes
+template <> float box_hi<float>(double v) { return up(v); }
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    DeviceScene<double> d64;
+    DeviceScene<float> d32;
+    int32_t n_lights = 0, n_prims = 0, n_ops = 0;
+    unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t lds_limit = 65536;
+};
+
+namespace {
+
+struct Flat {   // validated, precision-independent view of the description
+    std::vector<int32_t> op_prim, op_skip;
+    std::vector<double> op_box;   // 6 per op
+};
+
+int validate(const rt_scene_desc* d)
+{
+    if (!d) return fail(RT_EINVAL, "desc is NULL");
+    if (d->n_nodes < 0 || d->n_prims <= 0 || d->n_mats <= 0 || d->n_tex < 0 || d->n_lights < 0 || d->n_roots <= 0)
+        return fail(RT_EINVAL, "scene needs at least one primitive, material and root");
+    if ((d->n_nodes && (!d->node_bbox || !d->node_child)) || !d->roots || !d->prim_kind || !d->prim_flags || !d->prim_mat || !d->prim_data ||
+        !d->mat_kind || !d->mat_tex || !d->mat_data || (d->n_tex && (!d->tex_kind || !d->tex_data)) ||
+        (d->n_lights && (!d->light_kind || !d->light_flags || !d->light_data)))
+        return fail(RT_EINVAL, "a required array of the scene description is NULL");
+    auto code_ok = [&](int32_t c) { return c >= 0 ? c < d->n_nodes : (~c) < d->n_prims; };
+    for (int i = 0; i < d->n_roots; i++) if (!code_ok(d->roots[i])) return fail(RT_EINVAL, "root code out of range");
+    for (int i = 0; i < 2 * d->n_nodes; i++) if (!code_ok(d->node_child[i])) return fail(RT_EINVAL, "bvh child code out of range");
+    for (int i = 0; i < d->n_prims; i++) {
+        if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_TRIANGLE) return fail(RT_EINVAL, "unknown primitive kind");
+        if (d->prim_mat[i] < 0 || d->prim_mat[i] >= d->n_mats) return fail(RT_EINVAL, "primitive material index out of range");
+    }
+    for (int i = 0; i < d->n_lights; i++)
+        if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_TRIANGLE) return fail(RT_EINVAL, "unknown light kind");
+    for (int i = 0; i < d->n_mats; i++) {
+        int k = d->mat_kind[i], t = d->mat_tex[i];
+        if (k < RT_MAT_LAMBERTIAN || k > RT_MAT_PHONG) return fail(RT_EINVAL, "unknown material kind");
+        bool needs_tex = k == RT_MAT_LAMBERTIAN || k == RT_MAT_METAL || k == RT_MAT_EMISSIVE;
+        if (t >= d->n_tex || (needs_tex && t < 0)) return fail(RT_EINVAL, "material texture index out of range");
+    }
+    for (int i = 0; i < d->n_tex; i++) {
+        int k = d->tex_kind[i];
+        const double* td = d->tex_data + (size_t) i * RT_TEX_STRIDE;
+        if (k == RT_TEX_CHECKER) {
+            if (td[0] < 0 || td[0] >= d->n_tex || td[1] < 0 || td[1] >= d->n_tex) return fail(RT_EINVAL, "checker texture index out of range");
+        }
+        else if (k == RT_TEX_IMAGE) {
+            double w = td[0], h = td[1], ch = td[2], off = td[4];
+            if (w > 0 && (h <= 0 || ch < 3 || off < 0 || off + w * h * ch > (double) d->n_pixel_bytes || !d->tex_pixels))
+                return fail(RT_EINVAL, "image texture exceeds tex_pixels");
+        }
+        else if (k != RT_TEX_CONSTANT) return fail(RT_EINVAL, "unknown texture kind");
+    }
+    return RT_OK;
+}
+
+// pre-order program of the reference tree; iterative so a degenerate tree cannot overflow the host stack
+int linearize(const rt_scene_desc* d, Flat& f)
+{
+    struct Frame { int32_t code; int stage; int op; };
+    std::vector<Frame> stack;
+    size_t guard = (size_t) d->n_nodes * 3 + (size_t) d->n_roots + 16;
+    for (int r = 0; r < d->n_roots; r++) {
+        stack.push_back({ d->roots[r], 0, -1 });
+        while (!stack.empty()) {
+            Frame& fr = stack.back();
+            if (fr.code < 0) {
+                f.op_prim.push_back(~fr.code); f.op_skip.push_back(0);
+                for (int k = 0; k < 6; k++) f.op_box.push_back(0.0);
+                stack.pop_back();
+                continue;
+            }
+            if (fr.stage == 0) {
+                fr.op = (int) f.op_prim.size();
+                f.op_prim.push_back(-1); f.op_skip.push_back(0);
+                for (int k = 0; k < 6; k++) f.op_box.push_back(d->node_bbox[(size_t) fr.code * 6 + k]);
+                fr.stage = 1;
+                int32_t child = d->node_child[(size_t) fr.code * 2];
+                stack.push_back({ child, 0, -1 });
+            }
+            else if (fr.stage == 1) {
+                fr.stage = 2;
+                int32_t child = d->node_child[(size_t) fr.code * 2 + 1];
+                stack.push_back({ child, 0, -1 });
+            }
+            else {
+                f.op_skip[fr.op] = (int32_t) f.op_prim.size();
+                stack.pop_back();
+            }
+            if (f.op_prim.size() > guard) return fail(RT_EINVAL, "bvh links are not a tree (shared node or cycle)");
+        }
+    }
+    return RT_OK;
+}
+
+template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g)
+{
+    std::memset(&p, 0, sizeof p);
+    p.kind = kind; p.flags = flags; p.mat = mat;
+    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : 5;
+    for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
+    if (tri) {
+        std::memset(tri, 0, sizeof *tri);
+        if (kind == RT_PRIM_TRIANGLE) {
+            for (int k = 0; k < 9; k++) tri->n[k] = (R) g[9 + k];
+            for (int k = 0; k < 6; k++) tri->uv[k] = (R) g[18 + k];
+        }
+    }
+}
+
+template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, DeviceScene<R>& out)
+{
+    const int n_ops = (int) f.op_prim.size();
+    std::vector<rt::Op<R>> ops(n_ops);
+    for (int i = 0; i < n_ops; i++) {
+        for (int k = 0; k < 3; k++) { ops[i].mn[k] = box_lo<R>(f.op_box[(size_t) i * 6 + k]); ops[i].mx[k] = box_hi<R>(f.op_box[(size_t) i * 6 + 3 + k]); }
+        ops[i].skip = f.op_skip[i]; ops[i].prim = f.op_prim[i];
+    }
+    bool has_tri = false;
+    for (int i = 0; i < d->n_prims; i++) has_tri |= d->prim_kind[i] == RT_PRIM_TRIANGLE;
+    bool light_tri = false;
+    for (int i = 0; i < d->n_lights; i++) light_tri |= d->light_kind[i] == RT_PRIM_TRIANGLE;
+
+    std::vector<rt::Prim<R>> prims(d->n_prims);
+    std::vector<rt::TriShade<R>> tris(has_tri ? d->n_prims : 0);
+    for (int i = 0; i < d->n_prims; i++)
+        fill_prim<R>(prims[i], has_tri ? &tris[i] : nullptr, d->prim_kind[i], d->prim_flags[i], d->prim_mat[i], d->prim_data + (size_t) i * RT_PRIM_STRIDE);
+    std::vector<rt::Prim<R>> lights(d->n_lights);
+    std::vector<rt::TriShade<R>> ltris(light_tri ? d->n_lights : 0);
+    for (int i = 0; i < d->n_lights; i++)
+        fill_prim<R>(lights[i], light_tri ? &ltris[i] : nullptr, d->light_kind[i], d->light_flags[i], d->light_mat ? d->light_mat[i] : 0,
+                     d->light_data + (size_t) i * RT_PRIM_STRIDE);
+
+    std::vector<rt::Mat<R>> mats(d->n_mats);
+    for (int i = 0; i < d->n_mats; i++) {
+        mats[i].kind = d->mat_kind[i]; mats[i].tex = d->mat_tex[i];
+        for (int k = 0; k < RT_MAT_STRIDE; k++) mats[i].d[k] = (R) d->mat_data[(size_t) i * RT_MAT_STRIDE + k];
+    }
+    bool need_uv = false;
+    std::vector<rt::Tex<R>> texs(d->n_tex);
+    for (int i = 0; i < d->n_tex; i++) {
+        const double* td = d->tex_data + (size_t) i * RT_TEX_STRIDE;
+        rt::Tex<R>& t = texs[i];
+        std::memset(&t, 0, sizeof t);
+        t.kind = d->tex_kind[i];
+        if (t.kind == RT_TEX_CONSTANT) { t.rgb[0] = (R) td[0]; t.rgb[1] = (R) td[1]; t.rgb[2] = (R) td[2]; }
+        else if (t.kind == RT_TEX_CHECKER) { t.a = (int) td[0]; t.b = (int) td[1]; }
+        else { t.a = (int) td[0]; t.b = (int) td[1]; t.ch = (int) td[2]; t.color_based = td[3] != 0; t.offset = (uint32_t) td[4]; need_uv = true; }
+    }
+    std::vector<uint8_t> pixels(d->tex_pixels ? d->tex_pixels : nullptr, d->tex_pixels ? d->tex_pixels + d->n_pixel_bytes : nullptr);
+
+    rt::Scene<R>& v = out.view;
+    int rc;
+    if ((rc = upload(out.owned, ops, &v.ops))) return rc;
+    if ((rc = upload(out.owned, prims, &v.prims))) return rc;
+    if (has_tri) { if ((rc = upload(out.owned, tris, &v.tris))) return rc; } else v.tris = nullptr;
+    if ((rc = upload(out.owned, mats, &v.mats))) return rc;
+    if ((rc = upload(out.owned, texs, &v.texs))) return rc;
+    if ((rc = upload(out.owned, pixels, &v.pixels))) return rc;
+    if ((rc = upload(out.owned, lights, &v.lights))) return rc;
+    if (light_tri) { if ((rc = upload(out.owned, ltris, &v.light_tris))) return rc; } else v.light_tris = nullptr;
+    v.n_ops = n_ops; v.n_prims = d->n_prims; v.n_lights = d->n_lights; v.need_uv = need_uv;
+    const double* c = d->camera;
+    auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };
+    v.cam.pos = v3(0); v.cam.left_bottom = v3(3); v.cam.horizontal = v3(6); v.cam.vertical = v3(9); v.cam.u = v3(12); v.cam.v = v3(15);
+    v.cam.lens_radius = (R) c[21]; v.cam.s0 = (R) c[22]; v.cam.s1 = (R) c[23];
+    out.ops_bytes = (uint32_t) (((size_t) n_ops * sizeof(rt::Op<R>) + 15) / 16 * 16);
+    out.prims_bytes = (uint32_t) (((size_t) d->n_prims * sizeof(rt::Prim<R>) + 15) / 16 * 16);
+    return RT_OK;
+}
+
+template <typename R> void release(DeviceScene<R>& s)
+{
+    for (void* p : s.owned) (void) hipFree(p);
+    s.owned.clear();
+}
+
+__global__ void resolve_kernel(const void* accum, int is_fp64, size_t n_values, double inv_spp, uint8_t* rgb)
+{
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_values) return;
+    double c = is_fp64 ? static_cast<const double*>(accum)[i] : (double) static_cast<const float*>(accum)[i];
+    c = inv_spp * c;                                  // color /= spp  (vec3.hpp:56-58)   raytracing.cpp:115
+    c = pow(c, 0.45);                                 // gamma         raytracing.cpp:116
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);          // clamp         raytracing.cpp:117 (NaN falls through, as in util.hpp:119-130)
+    rgb[i] = (uint8_t) (int) (c * 255);               // truncation    raytracing.cpp:119-121
+}
+
+__global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    rt::Rng g; g.seed(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = g.next();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+const char* rt_version(void) { return "rtcore-mi355x 0.1 (gfx950)"; }
+
+int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
+{
+    if (!scene_out) return fail(RT_EINVAL, "scene_out is NULL");
+    *scene_out = nullptr;
+    int rc = validate(desc);
+    if (rc) return rc;
+    Flat f;
+    if ((rc = linearize(desc, f))) return rc;
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ENOMEM, "out of host memory");
+    hipError_t e = hipGetDevice(&s->device);
+    if (e != hipSuccess) { delete s; return fail(RT_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e) + " (no HIP device: the HIP path is the only path)"); }
+    if ((rc = build_device<double>(desc, f, s->d64)) || (rc = build_device<float>(desc, f, s->d32))) { rt_scene_destroy(s); return rc; }
+    s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
+    if (hipMalloc((void**) &s->counters, 2 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
+        hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
+    if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
+    *scene_out = s;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s)
+{
+    if (!s) return RT_OK;
+    release(s->d64); release(s->d32);
+    if (s->counters) (void) hipFree(s->counters);
+    if (s->ev0) (void) hipEventDestroy(s->ev0);
+    if (s->ev1) (void) hipEventDestroy(s->ev1);
+    delete s;
+    return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render_stats* stats)
+{
+    if (!s || !p || !accum_dev) return fail(RT_EINVAL, "scene, params and accum_dev are required");
+    if (p->width < 2 || p->height < 2) return fail(RT_EINVAL, "width and height must be >= 2 (raytracing.cpp:102 divides by width-1)");
+    if (p->y_begin < 0 || p->y_end > p->height || p->y_begin > p->y_end) return fail(RT_EINVAL, "row range outside the image");
+    if (p->spp_begin < 0 || p->spp_end < p->spp_begin) return fail(RT_EINVAL, "bad sample range");
+    if (p->max_depth < 0) return fail(RT_EINVAL, "max_depth < 0");
+    if ((long long) p->width * p->height >= (1LL << 31) / 3) return fail(RT_EINVAL, "image too large");
+    if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32) return fail(RT_EINVAL, "unknown mode");
+    if (s->n_lights <= 0)
+        return fail(RT_EINVAL, "scene.lights is empty: the reference indexes a null light list on the first diffuse hit (group.hpp:115-119)");
+    hipStream_t st = static_cast<hipStream_t>(p->stream);
+    rt::RenderArgs a{};
+    a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
+    a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 2 * sizeof(unsigned long long), st));
+    if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
+    if (p->mode == RT_MODE_REFERENCE_FP64) {
+        if ((size_t) s->d64.ops_bytes + s->d64.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d64.ops_bytes; a.lds_prims_bytes = s->d64.prims_bytes; }
+        HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
+    }
+    else {
+        if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
+        HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st));
+    }
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev1, st));
+        HIP_TRY(hipEventSynchronize(s->ev1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        unsigned long long c[2];
+        HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
+        stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream)
+{
+    if (!accum_dev || !rgb_dev || spp <= 0) return fail(RT_EINVAL, "accum_dev, rgb_dev and spp > 0 are required");
+    size_t n = n_pixels * 3;
+    if (n == 0) return RT_OK;
+    if (n > (size_t) 0x7fffffff * 256) return fail(RT_EINVAL, "image too large");
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), accum_dev,
+                       accum_is_fp64, n, 1 / (double) spp, rgb_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_first_hit(rt_scene* s, const double* rays, size_t n, int32_t* prim, double* t, int32_t* front, uint32_t* n_box, uint32_t* n_leaf,
+                 uint64_t* visit_hash)
+{
+    if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
+    if (n == 0) return RT_OK;
+    if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    double* d_rays = nullptr; void* d_out = nullptr;
+    const size_t per = 4 + 8 + 4 + 4 + 4 + 8;
+    HIP_TRY(hipMalloc((void**) &d_rays, n * 7 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, n * per);
+    if (e != hipSuccess) { (void) hipFree(d_rays); return fail(RT_EHIP, "hipMalloc failed"); }
+    char* b = static_cast<char*>(d_out);
+    double* d_t = reinterpret_cast<double*>(b);
+    unsigned long long* d_hash = reinterpret_cast<unsigned long long*>(b + n * 8);
+    int32_t* d_prim = reinterpret_cast<int32_t*>(b + n * 16);
+    int32_t* d_front = reinterpret_cast<int32_t*>(b + n * 20);
+    uint32_t* d_box = reinterpret_cast<uint32_t*>(b + n * 24);
+    uint32_t* d_leaf = reinterpret_cast<uint32_t*>(b + n * 28);
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipMemcpy(d_rays, rays, n * 7 * sizeof(double), hipMemcpyHostToDevice), "upload rays");
+    if (rc == RT_OK) chk(rt::launch_first_hit(s->d64.view, d_rays, (int) n, d_prim, d_t, d_front, d_box, d_leaf, d_hash, nullptr), "first_hit launch");
+    if (rc == RT_OK) chk(hipDeviceSynchronize(), "first_hit kernel");
+    if (rc == RT_OK && prim) chk(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && t) chk(hipMemcpy(t, d_t, n * 8, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && front) chk(hipMemcpy(front, d_front, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && n_box) chk(hipMemcpy(n_box, d_box, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && n_leaf) chk(hipMemcpy(n_leaf, d_leaf, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && visit_hash) chk(hipMemcpy(visit_hash, d_hash, n * 8, hipMemcpyDeviceToHost), "download");
+    (void) hipFree(d_rays); (void) hipFree(d_out);
+    return rc;
+}
+
+int rt_buffer_alloc(size_t bytes, void** dev_out)
+{
+    if (!dev_out) return fail(RT_EINVAL, "dev_out is NULL");
+    HIP_TRY(hipMalloc(dev_out, bytes ? bytes : 16));
+    return RT_OK;
+}
+int rt_buffer_free(void* dev) { if (dev) HIP_TRY(hipFree(dev)); return RT_OK; }
+int rt_buffer_download(void* host_dst, const void* dev_src, size_t bytes) { HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost)); return RT_OK; }
+int rt_buffer_upload(void* dev_dst, const void* host_src, size_t bytes) { HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice)); return RT_OK; }
+
+int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host)
+{
+    if (n <= 0 || !out_host) return fail(RT_EINVAL, "n > 0 and out_host are required");
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**) &d, (size_t) n * 4));
+    hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, nullptr, seed, pixel, sample, n, d);
+    hipError_t e = hipMemcpy(out_host, d, (size_t) n * 4, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return fail(RT_EHIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"
