@@ -226,6 +226,7 @@ struct orc_scene {
     const orc_obj** pre; int* pre_first; int* pre_left; int* pre_right; int n_pre;
     int* root_entry;
     uint64_t rays;
+    int early_exit;   /* stop a path once its sample is known to be rejected (same image, fewer rays) */
 };
 
 static v3 tex_color(const orc_scene* s, int ti, v3 p, v2 uv)
@@ -1126,6 +1127,13 @@ static v3 trace(orc_scene* s, orc_rng* g, const ray* wi, int depth, uint64_t* ra
         mpdf = mat_pdf(g, m, &x, &wo);
         pdf = 0.5 * (lights_pdf(s, x.pos, wo.d) + mpdf);
     }
+    if (s->early_exit) {
+        /* the sample is rejected (raytracing.cpp:108-110) whatever the rest of the path does: see the note in
+         * raytracing_amd/csrc/rt_device.h render_kernel; NaN makes the caller's test fire */
+        v3 w = smul(mpdf, att);
+        double inv = 1 / pdf;
+        if (!isfinite(inv) || !isfinite(w.x) || !isfinite(w.y) || !isfinite(w.z)) return V(NAN, NAN, NAN);
+    }
     v3 li = trace(s, g, &wo, depth - 1, rays);
     /* emission + attenuation * mat_pdf * L / pdf  ==  emission + (1/pdf) * ((mat_pdf*attenuation) (*) L) */
     return vadd(emission, sdiv(vmul(smul(mpdf, att), li), pdf));
@@ -1214,6 +1222,8 @@ void orc_render(orc_scene* s, int spp_begin, int spp_end, int max_depth, int rng
     counters[0] = rays; counters[1] = bad; counters[3] = 0;
     if (rgb_out) orc_resolve(sum_out, w * h, spp_end - spp_begin, rgb_out);
 }
+
+void orc_set_early_exit(orc_scene* s, int on) { s->early_exit = on; }
 
 /* ------------------------------------------------------------------ rng fills */
 void orc_glibc_rand_fill(unsigned seed, int n, int32_t* out)

@@ -192,6 +192,35 @@ template <typename R> __device__ inline bool sphere_t(const vec3<R>& center, R r
     return true;
 }
 
+// fp32 fast mode: `oc.oc - r*r` cancels catastrophically for a big sphere hit from its own surface (the r = 1000
+// ground sphere: absolute error ~0.06 in fp32 => self-intersections past t_min = 1e-3).  The three cancelling
+// quantities b, c and the discriminant are formed in fp64 (gfx950 runs vector fp64 at half the fp32 rate, and
+// leaf tests are ~1/7 of the box tests), everything else, including the sqrt and the roots, stays fp32; the
+// roots use the cancellation-free form q = -(b/2 + sign(b) sqrt(disc/4)), t0 = q/a, t1 = c/q.
+template <> __device__ inline bool sphere_t<float>(const vec3<float>& center, float radius, const Ray<float>& r, float t_min, float t_max, float& t)
+{
+    double ox = (double) r.o.x - (double) center.x, oy = (double) r.o.y - (double) center.y, oz = (double) r.o.z - (double) center.z;
+    double dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    double a = dx * dx + dy * dy + dz * dz;
+    double hb = ox * dx + oy * dy + oz * dz;                       // b / 2
+    double c = ox * ox + oy * oy + oz * oz - (double) radius * (double) radius;
+    double qd = hb * hb - a * c;                                    // disc / 4
+    if (qd < 0.0) return false;
+    float sq = sqrtf((float) qd);
+    float hbf = (float) hb, af = (float) a, cf = (float) c;
+    float q = hbf < 0.0f ? sq - hbf : -(hbf + sq);                  // -(b/2 + sign(b) sqrt(disc/4))
+    float r0 = q / af, r1 = cf / q;
+    float lo = fminf(r0, r1), hi = fmaxf(r0, r1);
+    if (q == 0.0f) { lo = hi = 0.0f; }
+    float root = lo;
+    if (root < t_min || root > t_max) {
+        root = hi;
+        if (root < t_min || root > t_max) return false;
+    }
+    t = root;
+    return true;
+}
+
 __device__ inline void plane_axes(int kind, int& ax, int& bx, int& kx)
 {
     if (kind == RT_PRIM_PLANEXY) { ax = 0; bx = 1; kx = 2; }

@@ -1,0 +1,46 @@
+// raytracing_amd/host/demo.hpp -- demo scenes (reference: src/cpp/demo.hpp:17-60 random_scene).
+// The rand() draws happen in the order the reference's g++ build makes them (arguments of a constructor call are
+// evaluated last-to-first), written out as statements here so the scene does not depend on the compiler.
+#pragma once
+
+#include "bvh.hpp"
+#include "group.hpp"
+#include "material.hpp"
+#include "primitive.hpp"
+#include "texture.hpp"
+#include "transform.hpp"
+#include "util.hpp"
+
+inline group random_scene()
+{
+    group grp;
+    grp.add(new sphere(vec3d(0, -1000, 0), 1000, new lambertian(new checker(vec3d(0, 0, 0), vec3d(1, 1, 1)))));
+    for (int i = -11; i < 11; i++) {
+        for (int j = -11; j < 11; j++) {
+            double choose = random_double();
+            double cz = j + 0.9 * random_double();
+            double cx = i + 0.9 * random_double();
+            vec3d center(cx, 0.2, cz);
+            if ((center - vec3d(4, 0.2, 0)).length() <= 0.9) continue;
+            if (choose < 0.8) {
+                vec3d second = random_vector();
+                vec3d first = random_vector();
+                material* m = new lambertian(first * second);
+                vec3d center2 = center + vec3d(0, random_double(0, 0.5), 0);
+                grp.add(new msphere(center, center2, 0, 1, 0.2, m));
+            }
+            else if (choose < 0.95) {
+                vec3d albedo = random_vector(0.5, 1);
+                double roughness = random_double(0, 0.5);
+                grp.add(new sphere(center, 0.2, new metal(albedo, roughness)));
+            }
+            else {
+                grp.add(new sphere(center, 0.2, new dielectric(1.5)));
+            }
+        }
+    }
+    grp.add(new sphere(vec3d(0, 1, 0), 1.0, new dielectric(1.5)));
+    grp.add(new sphere(vec3d(-4, 1, 0), 1.0, new lambertian(vec3d(0.4, 0.2, 0.1))));
+    grp.add(new sphere(vec3d(4, 1, 0), 1.0, new metal(vec3d(0.7, 0.6, 0.5), 0)));
+    return group(new bvh(grp, 0, 1));
+}

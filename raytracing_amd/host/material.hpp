@@ -1,0 +1,91 @@
+// raytracing_amd/host/material.hpp -- material classes (reference: src/cpp/material.hpp:9-312):
+// lambertian, metal, dielectric, emissive, phong.  Constructors and public fields match the reference so
+// scene code compiles unchanged; shading/pdf/emit run on the GPU (csrc/rt_device.h mat_shading / mat_pdf / mat_emit).
+#pragma once
+
+#include "algebra.hpp"
+#include "flatten.hpp"
+#include "texture.hpp"
+
+class material {
+public:
+    uint64_t serial = rt_next_serial();
+    virtual ~material() {}
+    virtual bool has_emission() const { return false; }
+    virtual void flatten(flattener& f, int id) const = 0;
+protected:
+    static double* slot(flattener& f, int id, int kind, int tex)
+    {
+        f.out.mat_kind[id] = kind; f.out.mat_tex[id] = tex;
+        return &f.out.mat_data[(size_t) id * RT_MAT_STRIDE];
+    }
+};
+
+class lambertian : public material {
+public:
+    texture* base_color;
+    lambertian(const vec3d& color) : base_color(new constant(color)) {}
+    lambertian(texture* tex) : base_color(tex) {}
+    void flatten(flattener& f, int id) const override { int t = f.texture_id(base_color); slot(f, id, RT_MAT_LAMBERTIAN, t); }
+};
+
+class metal : public material {
+public:
+    texture* base_color;
+    double roughness;
+    metal(const vec3d& color, double rough) : base_color(new constant(color)), roughness(rough < 1 ? rough : 1) {}
+    metal(texture* tex, double rough) : base_color(tex), roughness(rough < 1 ? rough : 1) {}
+    void flatten(flattener& f, int id) const override { int t = f.texture_id(base_color); slot(f, id, RT_MAT_METAL, t)[0] = roughness; }
+};
+
+class dielectric : public material {
+public:
+    double ior;
+    dielectric(double index) : ior(index) {}
+    void flatten(flattener& f, int id) const override { slot(f, id, RT_MAT_DIELECTRIC, -1)[0] = ior; }
+};
+
+class emissive : public material {
+public:
+    texture* emission;
+    emissive(texture* tex) : emission(tex) {}
+    emissive(const vec3d& color) : emission(new constant(color)) {}
+    bool has_emission() const override { return true; }
+    void flatten(flattener& f, int id) const override { int t = f.texture_id(emission); slot(f, id, RT_MAT_EMISSIVE, t); }
+};
+
+// the MTL material every OBJ face gets (reference loader.hpp:160)
+class phong : public material {
+public:
+    vec3d Kd = vec3d(0.9, 0.9, 0.9);
+    vec3d Ks = vec3d(0.0, 0.0, 0.0);
+    vec3d Ke = vec3d(0.0, 0.0, 0.0);
+    vec3d Tr = vec3d(0.0, 0.0, 0.0);
+    float Ns = 0.0;
+    float Ni = 0.0;
+    texture* diffuse_map = nullptr;
+    texture* normal_map = nullptr;
+
+    phong(const vec3d& color) { Kd = color; }
+    phong(texture* tex) { diffuse_map = tex; }
+    bool has_emission() const override { return Ke.x() > 0 || Ke.y() || Ke.z(); }
+    void flatten(flattener& f, int id) const override
+    {
+        int t = diffuse_map ? f.texture_id(diffuse_map) : -1;
+        double* d = slot(f, id, RT_MAT_PHONG, t);
+        for (int k = 0; k < 3; k++) { d[1 + k] = Kd[k]; d[4 + k] = Ks[k]; d[7 + k] = Ke[k]; d[10 + k] = Tr[k]; }
+        d[13] = Ns; d[14] = Ni;
+    }
+};
+
+inline int flattener::material_id(const material* m)
+{
+    auto it = mat_ids.find(m);
+    if (it != mat_ids.end()) return it->second;
+    int id = (int) out.mat_kind.size();
+    mat_ids[m] = id;
+    out.mat_kind.push_back(0); out.mat_tex.push_back(-1);
+    out.mat_data.resize(out.mat_data.size() + RT_MAT_STRIDE, 0.0);
+    m->flatten(*this, id);
+    return id;
+}

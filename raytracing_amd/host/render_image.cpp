@@ -1,0 +1,43 @@
+// raytracing_amd/host/render_image.cpp -- the reference's driver (src/cpp/raytracing.cpp:73-137) on the GPU core:
+// same scene-building statements, the pixel/sample loop replaced by scene::render().
+//   render_image [out.png] [width height spp max_depth] [scene.obj]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "rt_host.hpp"
+
+int main(int argc, char* argv[])
+{
+    const char* path = argc > 1 ? argv[1] : "./output.png";
+    int width = argc > 3 ? std::atoi(argv[2]) : 1200, height = argc > 3 ? std::atoi(argv[3]) : 800;
+    int spp = argc > 4 ? std::atoi(argv[4]) : 10, max_depth = argc > 5 ? std::atoi(argv[5]) : 50;
+
+    scene scn(width, height);
+    if (argc > 6) {
+        loader obj_loader(argv[6]);
+        scn.add_object(obj_loader.meshes());
+        scn.add_light(*obj_loader.lights());
+        scn.set_camera(camera(vec3d(0, 1.6, 4.2), vec3d(0, 0.6, 0), vec3d(0, 1, 0), 40, 1.78, 0, 1, 0, 1));
+    }
+    else {
+        object* light = new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4))));
+        scn.add_object(random_scene());
+        scn.add_object(new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4)))));
+        scn.add_light(light);
+        scn.set_camera(camera(vec3d(13, 2, 3), vec3d(0, 0, 0), vec3d(0, 1, 0), 20, 1.5, 0.1, 10, 0, 1));
+    }
+    scn.build_bvh();
+
+    std::printf("[INFO] start render...\n");
+    auto t0 = std::chrono::steady_clock::now();
+    rt_render_stats stats;
+    std::vector<unsigned char> data;
+    try { data = scn.render(spp, max_depth, true, 0, &stats); }
+    catch (const std::exception& e) { std::fprintf(stderr, "[ERROR] %s\n", e.what()); return 1; }
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!rt_write_png(path, width, height, 3, data.data(), true)) { std::fprintf(stderr, "[ERROR] can not write %s\n", path); return 1; }
+    std::printf("[INFO] render done, using %f sec (kernel %.3f ms, %.1f Mrays/s, %llu rays).\n", sec, stats.kernel_ms,
+                stats.rays / (stats.kernel_ms * 1e3), (unsigned long long) stats.rays);
+    return 0;
+}

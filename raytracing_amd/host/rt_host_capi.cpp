@@ -1,0 +1,104 @@
+// raytracing_amd/host/rt_host_capi.cpp -> librthost.so
+// C entry points over the C++ host mirror, for callers that are not C++ (bench.py, tests): build one of the
+// BASELINE workload scenes with the host classes, flatten it, hand back an rt_scene_desc whose arrays stay owned
+// by the returned handle.  No rendering here: the desc goes to librtcore.so (include/rtcore.h).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "rt_host.hpp"
+
+struct rth_scene {
+    flat_scene flat;
+    rt_scene_desc desc;
+    int width, height;
+};
+
+static thread_local std::string g_err;
+
+static rth_scene* finish(scene& scn, int w, int h)
+{
+    rth_scene* out = new rth_scene();
+    scn.flatten(out->flat);
+    out->desc = out->flat.desc();
+    out->width = w; out->height = h;
+    return out;
+}
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_err.c_str(); }
+
+// BASELINE configs 0/1: random_scene() + one overhead area light (the reference has no sky and needs >= 1 light,
+// SURVEY 9-2): flip(planexz(-20,20,-20,20,30, emissive(4,4,4))) as an object and, as a second instance, as the light
+// (the way raytracing.cpp:81-85 does for the Cornell box).  srand(seed) first: scene and tree come from rand().
+rth_scene* rth_build_random_spheres(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        scn.add_object(random_scene());
+        scn.add_object(new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4)))));
+        scn.add_light(new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4)))));
+        scn.set_camera(camera(vec3d(13, 2, 3), vec3d(0, 0, 0), vec3d(0, 1, 0), 20, double(width) / height, 0.1, 10, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+// OBJ scene through the loader: meshes -> objects, emissive faces -> lights, camera given by the caller
+rth_scene* rth_build_obj(const char* path, int width, int height, unsigned seed, const double cam_pos[3], const double cam_lookat[3], double fov)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        loader ld(path);
+        if (ld.meshes().size() == 0) { g_err = std::string("no triangles loaded from ") + path; return nullptr; }
+        scn.add_object(ld.meshes());
+        scn.add_light(*ld.lights());
+        scn.set_camera(camera(vec3d(cam_pos[0], cam_pos[1], cam_pos[2]), vec3d(cam_lookat[0], cam_lookat[1], cam_lookat[2]), vec3d(0, 1, 0), fov,
+                              double(width) / height, 0, 1, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+// the hand-made scene of the `mixed` fixture (every primitive and material kind in one tree)
+rth_scene* rth_build_mixed(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        group grp;
+        grp.add(new sphere(vec3d(0, -100.5, -1), 100, new lambertian(new checker(vec3d(0.2, 0.3, 0.1), vec3d(0.9, 0.9, 0.9)))));
+        grp.add(new sphere(vec3d(0, 0, -1), 0.5, new lambertian(vec3d(0.1, 0.2, 0.5))));
+        grp.add(new sphere(vec3d(-1.05, 0, -1), 0.5, new dielectric(1.5)));
+        grp.add(new sphere(vec3d(1.05, 0, -1), 0.5, new metal(vec3d(0.8, 0.6, 0.2), 0.3)));
+        grp.add(new msphere(vec3d(0.3, 0.7, -0.6), vec3d(0.3, 0.9, -0.6), 0, 1, 0.15, new lambertian(vec3d(0.7, 0.2, 0.2))));
+        grp.add(new sphere(vec3d(-0.4, -0.3, -0.2), 0.2, new metal(vec3d(0.9, 0.9, 0.9), 0.0)));
+        grp.add(new triangle(vec3d(-2, -0.5, -2.5), vec3d(2, -0.5, -2.5), vec3d(0, 2.0, -2.8), new lambertian(vec3d(0.3, 0.7, 0.3))));
+        grp.add(new triangle(vec3d(1.2, -0.5, 0.2), vec3d(1.9, -0.5, -0.4), vec3d(1.5, 0.6, -0.1), new metal(vec3d(0.7, 0.7, 0.9), 0.1)));
+        grp.add(new triangle(vec3d(-1.9, -0.5, 0.3), vec3d(-1.2, -0.5, 0.1), vec3d(-1.6, 0.5, 0.0), new phong(vec3d(0.6, 0.5, 0.2))));
+        grp.add(new planexy(-3, 3, -0.5, 3, -3.2, new lambertian(vec3d(0.6, 0.6, 0.7))));
+        grp.add(new planeyz(-0.5, 3, -3.2, 1, -3, new lambertian(vec3d(0.7, 0.3, 0.3))));
+        grp.add(new flip(new planexz(-1, 1, -2, 0, 3, new emissive(vec3d(6, 6, 6)))));
+        phong* lamp = new phong(vec3d(0, 0, 0));
+        lamp->Ke = vec3d(5, 4, 3);
+        triangle* lamp_tri = new triangle(vec3d(2.5, 2.5, -1.5), vec3d(2.5, 0.5, -0.5), vec3d(2.5, 0.5, -2.5), lamp);
+        grp.add(lamp_tri);
+        scn.add_object(grp);
+        scn.add_light(new flip(new planexz(-1, 1, -2, 0, 3, new emissive(vec3d(6, 6, 6)))));
+        scn.add_light(lamp_tri);
+        scn.set_camera(camera(vec3d(-0.5, 1.2, 3.5), vec3d(0, 0.2, -1), vec3d(0, 1, 0), 45, double(width) / height, 0.05, 4.5, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+const rt_scene_desc* rth_desc(const rth_scene* s) { return s ? &s->desc : nullptr; }
+void rth_free(rth_scene* s) { delete s; }
+
+}  // extern "C"

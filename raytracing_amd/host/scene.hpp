@@ -1,0 +1,101 @@
+// raytracing_amd/host/scene.hpp -- scene container (reference: src/cpp/scene.hpp:12-63), plus the boundary this
+// project inserts under it: flatten() -> rt_scene_desc -> rtcore C ABI -> HIP.
+//
+//   scene scn(w, h); scn.add_object(...); scn.add_light(...); scn.set_camera(cam); scn.build_bvh();   // as before
+//   std::vector<unsigned char> rgb = scn.render(spp, max_depth);                                       // new: GPU
+#pragma once
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bvh.hpp"
+#include "camera.hpp"
+#include "group.hpp"
+#include "rtcore.h"
+
+class scene {
+public:
+    group objects;
+    group* lights = new group();
+    camera render_camera;
+
+    scene() {}
+    scene(int w, int h) { set_size(w, h); }
+
+    void set_size(int w, int h) { width = w; height = h; fix_aspect(); }
+    vec2i get_size() { return vec2i(width, height); }
+    void set_camera(const camera& cam) { render_camera = cam; fix_aspect(); }
+    void add_object(const group& grp) { objects.add(grp); }
+    void add_object(object* obj) { objects.add(obj); }
+    void add_light(object* lgt) { lights->add(lgt); }
+    void add_light(const group& lgt) { lights->add(lgt); }
+
+    void build_bvh()
+    {
+        std::printf("[INFO] building bvh acceleration architecture...\n");
+        object* root = new bvh(objects);
+        objects = group(root);
+        std::printf("[INFO] bvh done.\n");
+    }
+
+    // object graph -> flat arrays.  `out` must outlive any rt_scene_desc taken from it.
+    void flatten(flat_scene& out) const
+    {
+        flattener f;
+        for (int i = 0; i < objects.size(); i++) f.collect(objects.content()[i]);
+        f.assign_prim_ids();
+        for (int i = 0; i < objects.size(); i++) f.out.roots.push_back(f.emit(objects.content()[i]));
+        for (int i = 0; i < lights->size(); i++) {
+            flat_leaf leaf;
+            if (!lights->content()[i]->leaf_record(leaf)) throw std::runtime_error("flatten: a light must be a primitive (optionally flipped)");
+            f.store_light(leaf);
+        }
+        render_camera.fields(f.out.camera);
+        out = std::move(f.out);
+    }
+
+    // Renders the frame on the current HIP device: the replacement for the pixel/sample loop of render_image
+    // (reference raytracing.cpp:96-123).  Returns width*height*3 bytes, row 0 = bottom row, ready for
+    // rt_write_png(..., flip_vertically = true).  fast = fp32 kernels, otherwise fp64 reference-order kernels.
+    std::vector<unsigned char> render(int spp, int max_depth, bool fast = true, unsigned long long seed = 0, rt_render_stats* stats_out = nullptr) const
+    {
+        flat_scene flat;
+        flatten(flat);
+        rt_scene_desc d = flat.desc();
+        rt_scene* dev = nullptr;
+        check(rt_scene_create(&d, &dev));
+        size_t n = (size_t) width * height * 3;
+        void *accum = nullptr, *rgb = nullptr;
+        std::vector<unsigned char> image(n);
+        try {
+            check(rt_buffer_alloc(n * (fast ? sizeof(float) : sizeof(double)), &accum));
+            check(rt_buffer_alloc(n, &rgb));
+            rt_render_params p;
+            p.width = width; p.height = height; p.y_begin = 0; p.y_end = height; p.spp_begin = 0; p.spp_end = spp; p.max_depth = max_depth;
+            p.mode = fast ? RT_MODE_FAST_FP32 : RT_MODE_REFERENCE_FP64; p.flags = 0; p.seed = seed; p.stream = nullptr;
+            rt_render_stats stats;
+            check(rt_render(dev, &p, accum, &stats));
+            if (stats_out) *stats_out = stats;
+            check(rt_resolve(accum, fast ? 0 : 1, (size_t) width * height, spp, static_cast<uint8_t*>(rgb), nullptr));
+            check(rt_buffer_download(image.data(), rgb, n));
+        }
+        catch (...) {
+            rt_buffer_free(accum); rt_buffer_free(rgb); rt_scene_destroy(dev);
+            throw;
+        }
+        rt_buffer_free(accum); rt_buffer_free(rgb); rt_scene_destroy(dev);
+        return image;
+    }
+
+private:
+    int width = 1280;
+    int height = 720;
+    static void check(int rc) { if (rc != RT_OK) throw std::runtime_error(std::string("rtcore: ") + rt_last_error()); }
+    void fix_aspect()   // the scene's size overrides the camera's aspect ratio (reference scene.hpp:57-62)
+    {
+        render_camera.aspect_ratio = double(width) / height;
+        render_camera.setup_camera();
+    }
+};

@@ -84,22 +84,27 @@ def test_render_fp64_matches_oracle_same_streams(R, golden_dir, name):
     osc.free()
 
 
-@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "obj"])
-def test_render_fp32_within_rmse_tolerance(R, golden_dir, name):
+@pytest.mark.parametrize("name,early", [("c0_seed1", 0), ("obj", 0), ("c0_seed1", 1), ("mixed", 1), ("obj", 1)])
+def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early):
     """fp32 fast mode vs the fp64 oracle on the same streams.  Tolerance: relative RMSE of the linear radiance <= 5 %
     at 16 spp (the Monte-Carlo noise of these small renders is ~30-60 %, so this is far inside the noise floor and only
-    leaves room for paths whose branches flip under fp32 rounding), and <= 2 % of 8-bit values off by more than 8 levels."""
+    leaves room for paths whose branches flip under fp32 rounding), <= 2 % of 8-bit values off by more than 8 levels,
+    ray counts within 1 %.  `mixed` is compared with early exit only: its phong-on-sphere paths continue, in the
+    reference, as zero-direction rays whose sphere roots are NaN (0/0) -- garbage the fp32 sphere test does not imitate
+    (the fp64 mode does, and is compared without early exit above)."""
     tag, make = SCENES[name]
     g, m = load(golden_dir, name)
     osc = make(golden_dir, m)
+    osc.set_early_exit(early)
     w, h, spp, depth = m["width"], m["height"], 16, min(m["depth"], 24)
     want, want_rgb, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=5, n_threads=8)
     sc = R.Scene(osc.export())
-    got, rgb, stats = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=5)
+    got, rgb, stats = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=5, flags=R.FLAG_EARLY_EXIT if early else 0)
     rmse = float(np.sqrt(np.mean((got - want) ** 2)) / max(np.sqrt(np.mean(want ** 2)), 1e-12))
     assert rmse < 0.05, rmse
     assert float((np.abs(rgb.astype(int) - want_rgb.astype(int)) > 8).mean()) < 0.02
-    assert abs(stats["rays"] - int(cnt[0])) <= 0.01 * int(cnt[0])
+    assert abs(stats["rays"] - int(cnt[0])) <= 0.01 * int(cnt[0]), (stats["rays"], int(cnt[0]))
+    assert abs(stats["rejected"] - int(cnt[1])) <= 0.02 * int(cnt[1]) + 8, (stats["rejected"], int(cnt[1]))
     sc.destroy()
     osc.free()
 
