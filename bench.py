@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the MI355X path-tracing core on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A *step* is one pass of the hot path over one frame: every rank renders its share of the frame's samples with the
+HIP kernels (rt_render), the per-rank fp32 accumulation buffers are summed onto rank 0 by an RCCL reduce over xGMI,
+and rank 0 resolves the frame (mean, gamma, clamp, 8-bit).  The samples of the frame are split over the ranks
+(spp split; RNG streams are keyed by the GLOBAL sample index, so the image does not depend on N): total work is
+fixed as N grows => "scaling": "strong".
+
+Workload at N=1 (config.workload): BASELINE configs[1] -- the reference's random_scene() (RTIOW final scene, ~485
+spheres, Lambertian/metal/dielectric) + the documented area light, 3840x2160, 1024 spp, max_depth 50, built by the
+C++ host mirror (raytracing_amd/host) exactly as the reference builds it (glibc rand() seed 1, reference BVH).
+Rays are counted by the kernel: trace() invocations that traverse the scene (raytracing.cpp:32-37).
+
+The one JSON line also carries
+  roofline      the render kernel against the chip's peaks: algorithmic work per launch / HIP-event duration;
+  cpu_baseline  the oracle (CPU restatement of the reference, fp64) timed on this box's host cores on a bounded
+                sample of the same workload -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic cost model of the dominant kernel (DESIGN.md "Measurement"): per box test 3 rcp + 6 sub + 6 mul +
+# 6 select-compare + 3 cmp = 24 flop and one 32-B node record; per leaf test ~40 flop (sphere: 3 dots, disc, sqrt,
+# div, range tests) and one 64-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
+FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
+BYTES_BOX, BYTES_LEAF = 32.0, 64.0
+PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+PEAK_LDS_GBS = 150000.0      # aggregate ds_read_b64/b128 rate, every CU streaming (MI355X_MICROARCH.md, LDS)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (split over the ranks)")
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--mode", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--workload", choices=["random_spheres", "obj"], default="random_spheres")
+    ap.add_argument("--obj", default=os.path.join(ROOT, "tests", "golden", "mesh_scene.obj"))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (kind 'port': CPU restatement of the reference, pinned bit-exact to it by tests/golden) on the host cores.
+    Bounded sample: the same scene, resolution and depth at --cpu-spp samples per pixel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = min(16, os.cpu_count() or 1)
+    s = O.Scene.c0(args.width, args.height, 1)
+    t0 = time.perf_counter()
+    _, _, cnt = s.render(0, args.cpu_spp, args.depth, O.RNG_COUNTER, seed=1, n_threads=cores, want_rgb=False)
+    dt = time.perf_counter() - t0
+    s.free()
+    return {"value": round(int(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"random_spheres {args.width}x{args.height}, {args.cpu_spp} spp, max_depth {args.depth}: "
+                      f"{int(cnt[0])} rays in {dt:.2f} s (fp64, OpenMP over rows, per-(pixel,sample) RNG streams)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import raytracing_amd as R
+    from raytracing_amd.host_scenes import HostScene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 needs one rank per GPU: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path is the only path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h, spp = args.width, args.height, args.spp
+    mode = R.MODE_FAST_FP32 if args.mode == "fp32" else R.MODE_REFERENCE_FP64
+    dtype = torch.float32 if args.mode == "fp32" else torch.float64
+    if args.workload == "random_spheres":
+        host = HostScene.random_spheres(w, h, 1)
+        workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
+    else:
+        host = HostScene.obj(args.obj, w, h, 1)
+        workload = f"OBJ scene {os.path.basename(args.obj)} through the loader, {w}x{h}, {spp} spp, max_depth {args.depth}"
+    scene = host.upload()
+
+    # this rank's share of the frame's samples
+    k0 = rank * spp // world
+    k1 = (rank + 1) * spp // world
+    accum = torch.zeros((h, w, 3), dtype=dtype, device="cuda")
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = scene.render(accum.data_ptr(), w, h, k0, k1, args.depth, mode, seed=1, stream=stream)   # syncs, returns kernel stats
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            R.resolve(accum.data_ptr(), args.mode == "fp64", w * h, spp, rgb.data_ptr(), stream=stream)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    kernel_ms = []
+    for _ in range(args.steps):
+        st = step()
+        rays += st["rays"]
+        kernel_ms.append(st["kernel_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        total_rays, elapsed = float(tot[0]), float(mx[1])
+    else:
+        total_rays = float(tot[0])
+
+    if rank == 0:
+        # test counts for the roofline: one diagnostic launch (counting kernel variant) on a 1-spp sample of this rank's work
+        probe = scene.render(accum.data_ptr(), w, h, k0, k0 + 1, args.depth, mode, seed=1, stream=stream, flags=R.FLAG_COUNT_TESTS)
+        box_per_ray = probe["box_tests"] / max(probe["rays"], 1)
+        leaf_per_ray = probe["leaf_tests"] / max(probe["rays"], 1)
+        rays_per_launch = rays / max(args.steps, 1)
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        flop_per_ray = box_per_ray * FLOP_BOX + leaf_per_ray * FLOP_LEAF + FLOP_SHADE
+        bytes_per_ray = box_per_ray * BYTES_BOX + leaf_per_ray * BYTES_LEAF
+        if args.mode == "fp64":
+            bytes_per_ray = box_per_ray * 56.0 + leaf_per_ray * 112.0
+        achieved_tflops = rays_per_launch * flop_per_ray / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_FP32_TFLOPS if args.mode == "fp32" else PEAK_FP32_TFLOPS / 2
+        roofline = {
+            "bound": "valu", "kernel": "rt::render_kernel", "achieved": round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved_tflops / peak, 4), "traffic": None,
+            "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
+            "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
+            "flop_per_ray": round(flop_per_ray, 1), "scene_bytes_per_ray": round(bytes_per_ray, 1),
+            "scene_fetch_GBs": round(rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9, 1),
+            "note": "scene (traversal program + primitives) is staged in LDS for this workload: HBM traffic is the frame buffer only; "
+                    "scene_fetch_GBs is the LDS-side algorithmic record traffic (LDS peak ~150 TB/s chip-wide, HBM 8 TB/s)",
+        }
+        out = {
+            "metric": "Mrays/s (node), path-traced frame; image RMSE vs reference CPU checked in tests/", "value": round(total_rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.mode == "fp32" else "f64",
+            "data": "synthetic (procedural scene from the reference's random_scene(), rand() seed 1)",
+            "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
+                       "parallelism": f"spp split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
+                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu and args.workload == "random_spheres":
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+
+    scene.destroy()
+    host.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,8 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_EARLY_EXIT 2     /* stop a path as soon as its sample is known to be rejected (NaN/inf, raytracing.cpp:108-110).
                                     Same image; fewer rays than the reference traces.  Off by default. */
 
+#define RT_FLAG_COUNT_TESTS 4    /* diagnostic: also count box and leaf tests (slower kernel variant); fills stats.box_tests / leaf_tests */
+
 typedef struct rt_render_params {
     int32_t width, height;       /* image size: pixel (j,i) -> sample position as raytracing.cpp:102-103 */
     int32_t y_begin, y_end;      /* rows rendered by this call (tile split); 0, height for the whole frame */
@@ -103,6 +105,8 @@ typedef struct rt_render_stats {
     uint64_t rays;               /* trace() invocations that traversed the scene (raytracing.cpp:32-37) */
     uint64_t rejected_samples;   /* samples zeroed by the NaN/inf test (raytracing.cpp:108-110) */
     double kernel_ms;            /* HIP-event time of the render kernel on params.stream */
+    uint64_t box_tests;          /* aabb::intersect calls (aabb.hpp:23-41), only with RT_FLAG_COUNT_TESTS */
+    uint64_t leaf_tests;         /* primitive intersect calls, only with RT_FLAG_COUNT_TESTS */
 } rt_render_stats;
 
 /* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit

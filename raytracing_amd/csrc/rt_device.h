@@ -341,7 +341,7 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
 struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; };
 
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
-template <typename R, bool kStats>
+template <typename R, int kStats>   // 0: none, 1: count box/leaf tests, 2: counts + visit-order hash
 __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const Ray<R>& r,
                                   R& t_hit, VisitStats* st)
 {
@@ -351,7 +351,7 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
     int i = 0;
     while (i < n_ops) {
         const Op<R> op = ops[i];
-        if (kStats) st->hash = (st->hash ^ (uint64_t) (uint32_t) i) * 0x100000001B3ULL;
+        if (kStats == 2) st->hash = (st->hash ^ (uint64_t) (uint32_t) i) * 0x100000001B3ULL;
         if (op.prim < 0) {
             if (kStats) st->n_box++;
             i = box_hit(op, r, t_min, closest) ? i + 1 : op.skip;
@@ -587,7 +587,7 @@ struct RenderArgs {
 // beta_{i+1} = beta_i (*) (1/pdf_i) * (mat_pdf_i * attenuation_i).  The reference's recursion multiplies the same
 // factors on the way back up, so a non-finite 1/pdf or weight anywhere poisons the whole sample, even when the
 // path later misses (0 * inf); `poisoned` carries that.
-template <typename R, bool kLds>
+template <typename R, bool kLds, bool kCount>
 __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -614,6 +614,7 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
     const bool in_image = j < a.width && i < a.y_end;
 
     unsigned long long n_rays = 0, n_rejected = 0;
+    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0;
     vec3<R> sum;
 
     if (in_image) {
@@ -644,7 +645,7 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
             // ---- one path segment: trace() body for the current depth
             n_rays++;
             R t;
-            int prim = closest_hit<R, false>(ops, sc.n_ops, prims, ray, t, nullptr);
+            int prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, ray, t, &vs);
             bool done = true;
             if (prim >= 0) {
                 Hit<R> h;
@@ -699,6 +700,12 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
         atomicAdd(&counters[0], n_rays);
         if (n_rejected) atomicAdd(&counters[1], n_rejected);
     }
+    if (kCount) {   // diagnostic launches only: per-lane 32-bit counts are ample for one launch's per-pixel work
+        unsigned long long nb = vs.n_box, nl = vs.n_leaf;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64); }
+        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); }
+    }
 }
 
 // ------------------------------------------------------------------ parity kernel: explicit rays, with visit statistics
@@ -715,7 +722,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
     r.time = R(p[6]);
     VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL;
     R t;
-    int hit = closest_hit<R, true>(sc.ops, sc.n_ops, sc.prims, r, t, &st);
+    int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, r, t, &st);
     prim[idx] = hit;
     t_out[idx] = hit >= 0 ? (double) t : 0.0;
     int f = -1;

@@ -9,18 +9,24 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a, RT_REAL*
     if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
     dim3 grid((unsigned) (tiles_x * tiles_y)), block(256);
     const size_t lds = (size_t) a.lds_ops_bytes + a.lds_prims_bytes;
+    const bool count = (a.flags & RT_FLAG_COUNT_TESTS) != 0;
     if (lds > 0) {
         static thread_local size_t configured = 0;
         if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, true, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             configured = lds;
         }
-        hipLaunchKernelGGL((render_kernel<RT_REAL, true>), grid, block, lds, s, sc, a, accum, counters);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, true, true>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, true, false>), grid, block, lds, s, sc, a, accum, counters);
     }
     else {
-        hipLaunchKernelGGL((render_kernel<RT_REAL, false>), grid, block, 0, s, sc, a, accum, counters);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, false, true>), grid, block, 0, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, false, false>), grid, block, 0, s, sc, a, accum, counters);
     }
     return hipGetLastError();
 }

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librtcore.so")
 
 MODE_REFERENCE_FP64, MODE_FAST_FP32 = 0, 1
-FLAG_ACCUMULATE, FLAG_EARLY_EXIT = 1, 2
+FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS = 1, 2, 4
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 
 EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_buffer_alloc", "rt_buffer_free",
@@ -44,7 +44,7 @@ class RenderParams(C.Structure):
 
 
 class RenderStats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("rejected_samples", C.c_uint64), ("kernel_ms", C.c_double)]
+    _fields_ = [("rays", C.c_uint64), ("rejected_samples", C.c_uint64), ("kernel_ms", C.c_double), ("box_tests", C.c_uint64), ("leaf_tests", C.c_uint64)]
 
 
 _lib = None
@@ -166,7 +166,8 @@ class Scene:
                          C.c_void_p(stream) if stream else None)
         st = RenderStats()
         _check(load_library().rt_render(self.h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st) if want_stats else None))
-        return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms)) if want_stats else None
+        return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms), box_tests=int(st.box_tests),
+                    leaf_tests=int(st.leaf_tests)) if want_stats else None
 
     def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0):
         """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats)."""
