@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # 6 select-compare + 3 cmp = 24 flop and one 32-B node record; per leaf test ~40 flop (sphere: 3 dots, disc, sqrt,
 # div, range tests) and one 64-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
 FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
-BYTES_BOX, BYTES_LEAF = 32.0, 64.0
+BYTES_BOX, BYTES_LEAF = 32.0, 64.0   # fast tree: one 64-B node record per two box tests
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_GBS = 150000.0      # aggregate ds_read_b64/b128 rate, every CU streaming (MI355X_MICROARCH.md, LDS)
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (split over the ranks)")
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--mode", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--mode", choices=["fp32", "fp32ref", "fp64"], default="fp32", help="fp32: fast SAH tree; fp32ref: reference tree in fp32; fp64: reference mode")
     ap.add_argument("--workload", choices=["random_spheres", "obj"], default="random_spheres")
     ap.add_argument("--obj", default=os.path.join(ROOT, "tests", "golden", "mesh_scene.obj"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -92,8 +92,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h, spp = args.width, args.height, args.spp
-    mode = R.MODE_FAST_FP32 if args.mode == "fp32" else R.MODE_REFERENCE_FP64
-    dtype = torch.float32 if args.mode == "fp32" else torch.float64
+    mode = {"fp32": R.MODE_FAST_FP32, "fp32ref": R.MODE_FP32_REFERENCE_TREE, "fp64": R.MODE_REFERENCE_FP64}[args.mode]
+    dtype = torch.float64 if args.mode == "fp64" else torch.float32
+    # the host mirror prints the reference's "[INFO] building bvh..." lines on stdout; keep stdout for the JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if args.workload == "random_spheres":
         host = HostScene.random_spheres(w, h, 1)
         workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
@@ -101,6 +105,8 @@ def main():
         host = HostScene.obj(args.obj, w, h, 1)
         workload = f"OBJ scene {os.path.basename(args.obj)} through the loader, {w}x{h}, {spp} spp, max_depth {args.depth}"
     scene = host.upload()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
 
     # this rank's share of the frame's samples
     k0 = rank * spp // world
@@ -157,7 +163,7 @@ def main():
         if args.mode == "fp64":
             bytes_per_ray = box_per_ray * 56.0 + leaf_per_ray * 112.0
         achieved_tflops = rays_per_launch * flop_per_ray / (avg_ms * 1e-3) / 1e12
-        peak = PEAK_FP32_TFLOPS if args.mode == "fp32" else PEAK_FP32_TFLOPS / 2
+        peak = PEAK_FP32_TFLOPS if args.mode != "fp64" else PEAK_FP32_TFLOPS / 2
         roofline = {
             "bound": "valu", "kernel": "rt::render_kernel", "achieved": round(achieved_tflops, 3), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved_tflops / peak, 4), "traffic": None,
@@ -171,7 +177,7 @@ def main():
         out = {
             "metric": "Mrays/s (node), path-traced frame; image RMSE vs reference CPU checked in tests/", "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.mode == "fp32" else "f64",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.mode == "fp64" else "f32",
             "data": "synthetic (procedural scene from the reference's random_scene(), rand() seed 1)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
                        "parallelism": f"spp split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",

@@ -1103,9 +1103,12 @@ void orc_first_hit(const orc_scene* s, int n, const double* rays, int32_t* entry
 }
 
 /* ------------------------------------------------------------------ integrator (raytracing.cpp:30-70) */
+static double* g_path_out = 0; static int g_path_n = 0, g_path_cap = 0;   /* orc_debug_path capture (single-threaded use) */
+
 static v3 trace(orc_scene* s, orc_rng* g, const ray* wi, int depth, uint64_t* rays)
 {
     if (depth <= 0) return V(0, 0, 0);
+    if (g_path_out && g_path_n < g_path_cap) { double* w = g_path_out + 7 * g_path_n++; w[0] = wi->o.x; w[1] = wi->o.y; w[2] = wi->o.z; w[3] = wi->d.x; w[4] = wi->d.y; w[5] = wi->d.z; w[6] = wi->time; }
     isect x; memset(&x, 0, sizeof x);
     (*rays)++;
     if (!group_hit(s->objects, s->n_objects, wi, &x)) return V(0, 0, 0);
@@ -1221,6 +1224,21 @@ void orc_render(orc_scene* s, int spp_begin, int spp_end, int max_depth, int rng
     }
     counters[0] = rays; counters[1] = bad; counters[3] = 0;
     if (rgb_out) orc_resolve(sum_out, w * h, spp_end - spp_begin, rgb_out);
+}
+
+/* rays (o, d, time) of the path of one (pixel, sample) stream in COUNTER mode; returns the number of rays */
+int orc_debug_path(orc_scene* s, int i, int j, int k, uint64_t seed, int max_depth, double* rays7, int cap)
+{
+    orc_rng g; memset(&g, 0, sizeof g);
+    counter_seed(&g, seed, (uint32_t) (i * s->width + j), (uint32_t) k);
+    double x = (double) (j + rnd(&g)) / (s->width - 1);
+    double y = (double) (i + rnd(&g)) / (s->height - 1);
+    ray r = camera_emit(s, &g, x, y);
+    uint64_t n = 0;
+    g_path_out = rays7; g_path_n = 0; g_path_cap = cap;
+    trace(s, &g, &r, max_depth, &n);
+    g_path_out = 0;
+    return g_path_n;
 }
 
 void orc_set_early_exit(orc_scene* s, int on) { s->early_exit = on; }

@@ -59,8 +59,19 @@ template <typename R> struct alignas(8) Op {
 // hot primitive record (intersection only).  g[]: sphere c,r | msphere c0,c1,start,end,r | plane a0,a1,b0,b1,k | triangle p0,e1,e2
 template <typename R> struct alignas(16) Prim {
     R g[12];
-    int32_t kind, flags, mat, pad;
+    int32_t kind, flags, mat, id;   // id: primitive id (index into tris[]); records may be stored in any order
 };
+// Fast-mode BVH node (64 B, one cache line): both children's boxes live in the parent, so one fetch decides both.
+// Child code c >= 0: inner node c; c < 0: leaf, ~c = first_record * 8 + (count - 1) into Scene::fprims (<= 8 records).
+struct alignas(16) BNode {
+    float lb[6];        // left  child box: min xyz, max xyz (rounded outward from fp64)
+    float rb[6];        // right child box
+    int32_t left, right;
+    int32_t pad[2];
+};
+#define RT_BVH_SENTINEL ((int32_t) 0x80000000)
+#define RT_BVH_STACK_MAX 64
+
 // cold triangle record (shading only): vertex normals and uvs
 template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
 template <typename R> struct Mat { int32_t kind, tex; R d[16]; };
@@ -76,10 +87,12 @@ template <typename R> struct Scene {
     const uint8_t* pixels;
     const Prim<R>* lights; const TriShade<R>* light_tris; int32_t n_lights;
     int32_t need_uv;                  // some material reads uv (image texture)
+    const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
     Camera<R> cam;
 };
 
-template <typename R> struct Ray { vec3<R> o, d; R time; };
+// `from`: id of the primitive the origin lies on (-1: none).  Only the fp32 modes read it, see prim_t.
+template <typename R> struct Ray { vec3<R> o, d; R time; int32_t from = -1; };
 
 // ------------------------------------------------------------------ counter-based RNG
 // PCG32 XSH-RR over a state hashed from (seed, pixel, sample): nothing is stored between samples or launches,
@@ -260,9 +273,31 @@ template <typename R> __device__ inline bool tri_t(const Prim<R>& p, const Ray<R
     return true;
 }
 
+// A ray that starts ON a sphere has the roots t = 0 and t = -2 (oc.d)/(d.d) exactly.  In fp64 the reference's t = 0
+// root comes out ~1e-16 and is cut by t_min = 1e-3; in fp32 the origin is only within ~1e-7 of the surface, and at
+// grazing angles c/q grows past t_min: the ray would re-hit its own sphere from the inside (measured: +3.6 % rays,
+// paths trapped in the glass spheres).  So the fp32 modes take the non-zero root algebraically for the sphere the ray
+// starts on, and skip planar primitives the ray starts on (their only root is the t = 0 one).  fp64 mode: untouched.
+__device__ inline bool sphere_from_surface(const vec3<float>& center, const Ray<float>& r, float t_min, float t_max, float& t)
+{
+    vec3<float> oc = r.o - center;
+    float a = dot(r.d, r.d), hb = dot(oc, r.d);
+    float root = -2.0f * hb / a;
+    if (!(root >= t_min && root <= t_max)) return false;
+    t = root;
+    return true;
+}
+
 template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t)
 {
     R a, b;
+    if constexpr (sizeof(R) == sizeof(float)) {
+        if (p.id == r.from) {
+            if (p.kind == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
+            if (p.kind == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
+            return false;
+        }
+    }
     switch (p.kind) {
     case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
@@ -276,6 +311,7 @@ template <typename R> struct Hit {
     vec3<R> pos, normal;
     R u, v, t;
     int32_t mat;
+    int32_t id;        // primitive id of the hit
     bool front;
 };
 
@@ -287,11 +323,12 @@ template <typename R> __device__ inline void set_face_normal(Hit<R>& h, const Ra
 
 // Completes the record of a hit already known to lie at t on primitive p: the statements after the range test in
 // each intersect() (primitive.hpp:49-55, 123-129, 189-198; polygon.hpp:117-123; flip transform.hpp:134).
-template <typename R> __device__ inline void fill_record(const Prim<R>& p, const TriShade<R>* tris, int prim_index, const Ray<R>& r, R t,
+template <typename R> __device__ inline void fill_record(const Prim<R>& p, const TriShade<R>* tris, const Ray<R>& r, R t,
                                                          bool need_uv, Hit<R>& h)
 {
     h.t = t;
     h.mat = p.mat;
+    h.id = p.id;
     h.u = h.v = R(0);
     switch (p.kind) {
     case RT_PRIM_SPHERE:
@@ -313,7 +350,7 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
         R tt, u, v;
         tri_t(p, r, -rt_inf<R>(), rt_inf<R>(), tt, u, v);                   // same arithmetic as the accepted test
         h.pos = r.o + t * r.d;
-        const TriShade<R>& s = tris[prim_index];
+        const TriShade<R>& s = tris[p.id];
         R w = R(1) - u - v;
         h.u = (u * s.uv[2] + v * s.uv[4]) + w * s.uv[0];                    // polygon.hpp:174-177
         h.v = (u * s.uv[3] + v * s.uv[5]) + w * s.uv[1];
@@ -362,6 +399,68 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
             if (prim_t(prims[op.prim], r, t_min, closest, t)) { closest = t; hit = op.prim; }
             i++;
         }
+    }
+    t_hit = closest;
+    return hit;
+}
+
+
+// ------------------------------------------------------------------ fast mode: ordered stack traversal of the library's own SAH tree
+// Same closest hit as the reference's walk (the closest hit does not depend on visit order), far fewer tests.
+// "while-while" form: every lane first descends inner nodes until it holds a leaf, then the wave tests leaves
+// together, so box-test and primitive-test instructions are not interleaved per lane.  The per-lane stack of
+// postponed far children lives in LDS, one dword per level, lane-interleaved (entry `level*256 + tid`) so a
+// wave's pushes/pops hit 64 consecutive banks.
+__device__ inline void slab2(const float* b, const vec3<float>& o, const vec3<float>& idir, float t_min, float t_max, float& t_near, bool& hit)
+{
+    float x0 = (b[0] - o.x) * idir.x, x1 = (b[3] - o.x) * idir.x;
+    float y0 = (b[1] - o.y) * idir.y, y1 = (b[4] - o.y) * idir.y;
+    float z0 = (b[2] - o.z) * idir.z, z1 = (b[5] - o.z) * idir.z;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+    t_near = tn;
+    hit = tn <= tf * 1.0000004f;     // two-ulp slack keeps the culling conservative under fp32 rounding
+}
+
+template <int kStats>
+__device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, const Ray<float>& r, float& t_hit,
+                                      uint32_t* stack, VisitStats* st)
+{
+    const float t_min = consts<float>::tmin;
+    float closest = rt_inf<float>();
+    int hit = -1;
+    // a zero direction component would make 0 * inf = NaN in the slab test: nudge it (box tests only)
+    auto safe = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; };
+    const vec3<float> idir(1.0f / safe(r.d.x), 1.0f / safe(r.d.y), 1.0f / safe(r.d.z));
+    int sp = 0;
+    stack[0] = (uint32_t) RT_BVH_SENTINEL;
+    int32_t cur = 0;
+    while (cur != RT_BVH_SENTINEL) {
+        while (cur >= 0) {
+            const BNode n = nodes[cur];
+            float tl, tr; bool hl, hr;
+            slab2(n.lb, r.o, idir, t_min, closest, tl, hl);
+            slab2(n.rb, r.o, idir, t_min, closest, tr, hr);
+            if (kStats) st->n_box += 2;
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                int32_t far = left_first ? n.right : n.left;
+                cur = left_first ? n.left : n.right;
+                sp++;
+                stack[sp * 256] = (uint32_t) far;
+            }
+            else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else { cur = (int32_t) stack[sp * 256]; sp--; }
+        }
+        if (cur == RT_BVH_SENTINEL) break;
+        const int code = ~cur, first = code >> 3, count = (code & 7) + 1;
+        for (int k = 0; k < count; k++) {
+            float t;
+            if (kStats) st->n_leaf++;
+            if (prim_t(prims[first + k], r, t_min, closest, t)) { closest = t; hit = first + k; }
+        }
+        cur = (int32_t) stack[sp * 256]; sp--;
     }
     t_hit = closest;
     return hit;
@@ -441,13 +540,13 @@ template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng
     switch (m.kind) {
     case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
         spec = false;
-        wo.o = h.pos; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
+        wo.o = h.pos; wo.from = h.id; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
         att = tex_color(sc, m.tex, h.pos, h.u, h.v);
         return true;
     case RT_MAT_METAL: {                                                                    // material.hpp:74-82
         vec3<R> next = reflect(normalize(wi.d), h.normal);
         vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
-        wo.o = h.pos; wo.d = next + fuzz; wo.time = wi.time;
+        wo.o = h.pos; wo.from = h.id; wo.d = next + fuzz; wo.time = wi.time;
         att = tex_color(sc, m.tex, h.pos, h.u, h.v);
         spec = true;
         return true;
@@ -455,7 +554,7 @@ template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng
     case RT_MAT_DIELECTRIC:                                                                 // material.hpp:105-125
         spec = true;
         att = vec3<R>(R(1), R(1), R(1));
-        wo.o = h.pos; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
+        wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
         return true;
     case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
@@ -468,7 +567,7 @@ template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng
         if (nz3(m.d + 10)) {
             spec = true;
             att = vec3<R>(m.d[10], m.d[11], m.d[12]);
-            wo.o = h.pos; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
+            wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
             return true;
         }
         spec = false;
@@ -575,6 +674,7 @@ struct RenderArgs {
     int32_t width, height, y_begin, y_end, spp_begin, spp_end, max_depth, flags;
     uint64_t seed;
     uint32_t lds_ops_bytes, lds_prims_bytes;   // 0: read the traversal program from global memory
+    uint32_t bvh_stack_levels;                 // > 0: fast mode, LDS stack of this many dwords per lane
 };
 
 // ------------------------------------------------------------------ render kernel
@@ -587,13 +687,14 @@ struct RenderArgs {
 // beta_{i+1} = beta_i (*) (1/pdf_i) * (mat_pdf_i * attenuation_i).  The reference's recursion multiplies the same
 // factors on the way back up, so a non-finite 1/pdf or weight anywhere poisons the whole sample, even when the
 // path later misses (0 * inf); `poisoned` carries that.
-template <typename R, bool kLds, bool kCount>
+// kTrav: 0 reference-order program in global memory, 1 the same staged in LDS, 2 fast-mode SAH tree (fp32 only)
+template <typename R, int kTrav, bool kCount>
 __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const Op<R>* ops = sc.ops;
     const Prim<R>* prims = sc.prims;
-    if (kLds) {
+    if (kTrav == 1) {
         // stage the whole traversal program into LDS: 16-byte copies, all 256 threads
         const uint4* src0 = reinterpret_cast<const uint4*>(sc.ops);
         uint4* dst0 = reinterpret_cast<uint4*>(smem);
@@ -645,11 +746,13 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
             // ---- one path segment: trace() body for the current depth
             n_rays++;
             R t;
-            int prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, ray, t, &vs);
+            int prim;
+            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs);
+            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, ray, t, &vs);
             bool done = true;
             if (prim >= 0) {
                 Hit<R> h;
-                fill_record(prims[prim], sc.tris, prim, ray, t, sc.need_uv != 0, h);
+                fill_record(kTrav == 2 ? sc.fprims[prim] : prims[prim], sc.tris, ray, t, sc.need_uv != 0, h);
                 const Mat<R>& m = sc.mats[h.mat];
                 vec3<R> emission = mat_emit(sc, m, h);
                 Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
@@ -663,7 +766,7 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
                         pdf = mpdf;
                     }
                     else {                                                                  // raytracing.cpp:55-61
-                        if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                        if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
                         mpdf = mat_pdf(g, m, h, wo);
                         pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
                     }
@@ -685,6 +788,7 @@ __global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, 
             }
         }
 
+        if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) sum = vec3<R>(R((double) n_rays), R((double) n_rejected), R(0));
         R* out = accum + (size_t) pixel * 3;
         if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sum.x; out[1] += sum.y; out[2] += sum.z; }
         else { out[0] = sum.x; out[1] = sum.y; out[2] = sum.z; }
@@ -728,11 +832,31 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
     int f = -1;
     if (hit >= 0) {
         Hit<R> h;
-        fill_record(sc.prims[hit], sc.tris, hit, r, t, false, h);
+        fill_record(sc.prims[hit], sc.tris, r, t, false, h);
         f = h.front ? 1 : 0;
     }
     front[idx] = f;
     n_box[idx] = st.n_box; n_leaf[idx] = st.n_leaf; hash[idx] = st.hash;
 }
+
+
+#ifdef RT_WITH_FAST_BVH
+// fast-mode closest hit of explicit rays (test hook): primitive id and t only (defined in the fp32 translation unit only)
+__global__ void __launch_bounds__(256) first_hit_fast_kernel(Scene<float> sc, const double* __restrict__ rays, int n, int32_t* prim, float* t_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double* p = rays + (size_t) idx * 7;
+    Ray<float> r;
+    r.o = vec3<float>((float) p[0], (float) p[1], (float) p[2]);
+    r.d = vec3<float>((float) p[3], (float) p[4], (float) p[5]);
+    r.time = (float) p[6];
+    float t;
+    int hit = closest_hit_bvh<0>(sc.bnodes, sc.fprims, r, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, nullptr);
+    prim[idx] = hit >= 0 ? sc.fprims[hit].id : -1;
+    t_out[idx] = hit >= 0 ? t : 0.0f;
+}
+#endif
 
 }  // namespace rt

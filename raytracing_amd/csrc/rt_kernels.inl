@@ -10,26 +10,44 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a, RT_REAL*
     dim3 grid((unsigned) (tiles_x * tiles_y)), block(256);
     const size_t lds = (size_t) a.lds_ops_bytes + a.lds_prims_bytes;
     const bool count = (a.flags & RT_FLAG_COUNT_TESTS) != 0;
+#ifdef RT_WITH_FAST_BVH
+    if (a.bvh_stack_levels > 0) {
+        const size_t stack_bytes = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 2, true>), grid, block, stack_bytes, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, 2, false>), grid, block, stack_bytes, s, sc, a, accum, counters);
+        return hipGetLastError();
+    }
+#endif
     if (lds > 0) {
         static thread_local size_t configured = 0;
         if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, true, false>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, true, true>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
             configured = lds;
         }
-        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, true, true>), grid, block, lds, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_kernel<RT_REAL, true, false>), grid, block, lds, s, sc, a, accum, counters);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 1, true>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, 1, false>), grid, block, lds, s, sc, a, accum, counters);
     }
     else {
-        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, false, true>), grid, block, 0, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_kernel<RT_REAL, false, false>), grid, block, 0, s, sc, a, accum, counters);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 0, true>), grid, block, 0, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, 0, false>), grid, block, 0, s, sc, a, accum, counters);
     }
     return hipGetLastError();
 }
+
+#ifdef RT_WITH_FAST_BVH
+hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int n, int32_t* prim, float* t, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t stack_bytes = (size_t) (sc.bvh_depth + 2) * 256 * sizeof(uint32_t);
+    hipLaunchKernelGGL(first_hit_fast_kernel, dim3((n + 255) / 256), dim3(256), stack_bytes, s, sc, rays, n, prim, t);
+    return hipGetLastError();
+}
+#endif
 
 #ifdef RT_WITH_FIRST_HIT
 hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,

@@ -1,3 +1,4 @@
 // fp32 fast kernels (FMA contraction allowed).
 #define RT_REAL float
+#define RT_WITH_FAST_BVH 1
 #include "rt_kernels.inl"

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_bvh_build.h"
 #include "rt_launch.h"
 #include "rtcore.h"
 
@@ -73,7 +74,7 @@ struct rt_scene {
     int32_t n_lights = 0, n_prims = 0, n_ops = 0;
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    size_t lds_limit = 65536;
+    size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
 namespace {
@@ -162,10 +163,10 @@ int linearize(const rt_scene_desc* d, Flat& f)
     return RT_OK;
 }
 
-template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g)
+template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g, int id)
 {
     std::memset(&p, 0, sizeof p);
-    p.kind = kind; p.flags = flags; p.mat = mat;
+    p.kind = kind; p.flags = flags; p.mat = mat; p.id = id;
     int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : 5;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
     if (tri) {
@@ -175,6 +176,83 @@ template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int k
             for (int k = 0; k < 6; k++) tri->uv[k] = (R) g[18 + k];
         }
     }
+}
+
+// bounds of a primitive over the time span its rays can carry (camera shutter, hull with the primitive's own span)
+void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
+{
+    const double* g = d->prim_data + (size_t) i * RT_PRIM_STRIDE;
+    auto sphere = [&](const double c[3], double r) { double lo[3] = { c[0] - r, c[1] - r, c[2] - r }, hi[3] = { c[0] + r, c[1] + r, c[2] + r }; b.grow(lo); b.grow(hi); };
+    switch (d->prim_kind[i]) {
+    case RT_PRIM_SPHERE: sphere(g, std::fabs(g[3])); break;
+    case RT_PRIM_MSPHERE: {
+        double t0 = std::min(std::min(d->camera[22], d->camera[23]), std::min(g[6], 0.0));
+        double t1 = std::max(std::max(d->camera[22], d->camera[23]), std::max(g[7], 0.0));
+        for (double t : { t0, t1 }) {
+            double f = (t - g[6]) / (g[7] - g[6]);
+            if (!std::isfinite(f)) f = 0;
+            double c[3] = { g[0] + f * (g[3] - g[0]), g[1] + f * (g[4] - g[1]), g[2] + f * (g[5] - g[2]) };
+            sphere(c, std::fabs(g[8]));
+        }
+        break;
+    }
+    case RT_PRIM_TRIANGLE:
+        for (int v = 0; v < 3; v++) {
+            double p[3];
+            for (int k = 0; k < 3; k++) p[k] = g[k] + (v == 1 ? g[3 + k] : v == 2 ? g[6 + k] : 0.0);
+            b.grow(p);
+        }
+        break;
+    default: {
+        int ax = d->prim_kind[i] == RT_PRIM_PLANEYZ ? 1 : 0, bx = d->prim_kind[i] == RT_PRIM_PLANEXY ? 1 : 2;
+        int kx = 3 - ax - bx;
+        double lo[3], hi[3];
+        lo[ax] = g[0]; hi[ax] = g[1]; lo[bx] = g[2]; hi[bx] = g[3]; lo[kx] = g[4]; hi[kx] = g[4];
+        b.grow(lo); b.grow(hi);
+        break;
+    }
+    }
+    for (int k = 0; k < 3; k++) {   // pad flat boxes (rects, axis-aligned triangles) like the reference pads them (primitive.hpp:203, polygon.hpp:128)
+        double pad = 1e-4 + 1e-6 * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+        b.lo[k] -= pad; b.hi[k] += pad;
+    }
+}
+
+template <typename R> int build_fast_tree(const rt_scene_desc*, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out)
+{
+    out.view.bnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
+    return RT_OK;
+}
+template <> int build_fast_tree<float>(const rt_scene_desc* d, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out)
+{
+    std::vector<rtb::Item> items(d->n_prims);
+    for (int i = 0; i < d->n_prims; i++) {
+        prim_bounds(d, i, items[i].box);
+        for (int k = 0; k < 3; k++) items[i].c[k] = 0.5 * (items[i].box.lo[k] + items[i].box.hi[k]);
+        items[i].id = i;
+    }
+    int leaf_max = 4; double c_prim = 1.5;
+    if (const char* e = std::getenv("RT_BVH_LEAF")) leaf_max = std::atoi(e);
+    if (const char* e = std::getenv("RT_BVH_CPRIM")) c_prim = std::atof(e);
+    rtb::Tree tree = rtb::Builder(items, leaf_max, c_prim).build();
+    if (tree.depth + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode tree deeper than the traversal stack");
+    std::vector<rt::BNode> nodes(tree.nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        std::memset(&nodes[i], 0, sizeof(rt::BNode));
+        for (int k = 0; k < 3; k++) {
+            nodes[i].lb[k] = down(tree.nodes[i].lbox.lo[k]); nodes[i].lb[3 + k] = up(tree.nodes[i].lbox.hi[k]);
+            nodes[i].rb[k] = down(tree.nodes[i].rbox.lo[k]); nodes[i].rb[3 + k] = up(tree.nodes[i].rbox.hi[k]);
+        }
+        nodes[i].left = tree.nodes[i].left; nodes[i].right = tree.nodes[i].right;
+    }
+    std::vector<rt::Prim<float>> ordered(tree.order.size());
+    for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree.order[i]];
+    int rc;
+    if ((rc = upload(out.owned, nodes, &out.view.bnodes))) return rc;
+    if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
+    out.view.n_bnodes = (int32_t) nodes.size();
+    out.view.bvh_depth = tree.depth;
+    return RT_OK;
 }
 
 template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, DeviceScene<R>& out)
@@ -193,12 +271,12 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     std::vector<rt::Prim<R>> prims(d->n_prims);
     std::vector<rt::TriShade<R>> tris(has_tri ? d->n_prims : 0);
     for (int i = 0; i < d->n_prims; i++)
-        fill_prim<R>(prims[i], has_tri ? &tris[i] : nullptr, d->prim_kind[i], d->prim_flags[i], d->prim_mat[i], d->prim_data + (size_t) i * RT_PRIM_STRIDE);
+        fill_prim<R>(prims[i], has_tri ? &tris[i] : nullptr, d->prim_kind[i], d->prim_flags[i], d->prim_mat[i], d->prim_data + (size_t) i * RT_PRIM_STRIDE, i);
     std::vector<rt::Prim<R>> lights(d->n_lights);
     std::vector<rt::TriShade<R>> ltris(light_tri ? d->n_lights : 0);
     for (int i = 0; i < d->n_lights; i++)
         fill_prim<R>(lights[i], light_tri ? &ltris[i] : nullptr, d->light_kind[i], d->light_flags[i], d->light_mat ? d->light_mat[i] : 0,
-                     d->light_data + (size_t) i * RT_PRIM_STRIDE);
+                     d->light_data + (size_t) i * RT_PRIM_STRIDE, i);
 
     std::vector<rt::Mat<R>> mats(d->n_mats);
     for (int i = 0; i < d->n_mats; i++) {
@@ -233,6 +311,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };
     v.cam.pos = v3(0); v.cam.left_bottom = v3(3); v.cam.horizontal = v3(6); v.cam.vertical = v3(9); v.cam.u = v3(12); v.cam.v = v3(15);
     v.cam.lens_radius = (R) c[21]; v.cam.s0 = (R) c[22]; v.cam.s1 = (R) c[23];
+    if ((rc = build_fast_tree(d, prims, out))) return rc;
     out.ops_bytes = (uint32_t) (((size_t) n_ops * sizeof(rt::Op<R>) + 15) / 16 * 16);
     out.prims_bytes = (uint32_t) (((size_t) d->n_prims * sizeof(rt::Prim<R>) + 15) / 16 * 16);
     return RT_OK;
@@ -309,7 +388,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     if (p->spp_begin < 0 || p->spp_end < p->spp_begin) return fail(RT_EINVAL, "bad sample range");
     if (p->max_depth < 0) return fail(RT_EINVAL, "max_depth < 0");
     if ((long long) p->width * p->height >= (1LL << 31) / 3) return fail(RT_EINVAL, "image too large");
-    if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32) return fail(RT_EINVAL, "unknown mode");
+    if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32 && p->mode != RT_MODE_FP32_REFERENCE_TREE) return fail(RT_EINVAL, "unknown mode");
     if (s->n_lights <= 0)
         return fail(RT_EINVAL, "scene.lights is empty: the reference indexes a null light list on the first diffuse hit (group.hpp:115-119)");
     hipStream_t st = static_cast<hipStream_t>(p->stream);
@@ -323,7 +402,8 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
     }
     else {
-        if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
+        if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) s->d32.view.bvh_depth + 2;
+        else if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
         HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st));
     }
     if (stats) {
@@ -380,6 +460,26 @@ int rt_first_hit(rt_scene* s, const double* rays, size_t n, int32_t* prim, doubl
     if (rc == RT_OK && n_leaf) chk(hipMemcpy(n_leaf, d_leaf, n * 4, hipMemcpyDeviceToHost), "download");
     if (rc == RT_OK && visit_hash) chk(hipMemcpy(visit_hash, d_hash, n * 8, hipMemcpyDeviceToHost), "download");
     (void) hipFree(d_rays); (void) hipFree(d_out);
+    return rc;
+}
+
+int rt_first_hit_fast(rt_scene* s, const double* rays, size_t n, int32_t* prim, float* t)
+{
+    if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
+    if (n == 0) return RT_OK;
+    if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    double* d_rays = nullptr; int32_t* d_prim = nullptr; float* d_t = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipMalloc((void**) &d_rays, n * 7 * sizeof(double)), "hipMalloc");
+    chk(hipMalloc((void**) &d_prim, n * 4), "hipMalloc");
+    chk(hipMalloc((void**) &d_t, n * 4), "hipMalloc");
+    if (rc == RT_OK) chk(hipMemcpy(d_rays, rays, n * 7 * sizeof(double), hipMemcpyHostToDevice), "upload rays");
+    if (rc == RT_OK) chk(rt::launch_first_hit_fast(s->d32.view, d_rays, (int) n, d_prim, d_t, nullptr), "first_hit_fast launch");
+    if (rc == RT_OK) chk(hipDeviceSynchronize(), "first_hit_fast kernel");
+    if (rc == RT_OK && prim) chk(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && t) chk(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost), "download");
+    (void) hipFree(d_rays); (void) hipFree(d_prim); (void) hipFree(d_t);
     return rc;
 }
 

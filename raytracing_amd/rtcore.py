@@ -10,11 +10,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librtcore.so")
 
-MODE_REFERENCE_FP64, MODE_FAST_FP32 = 0, 1
-FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS = 1, 2, 4
+MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE = 0, 1, 2
+FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS = 1, 2, 4, 8
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 
-EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_buffer_alloc", "rt_buffer_free",
+EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_fast", "rt_buffer_alloc", "rt_buffer_free",
            "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version"]
 
 
@@ -65,6 +65,7 @@ def load_library():
         L.rt_resolve.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_first_hit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.rt_first_hit_fast.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.rt_buffer_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.rt_buffer_free.argtypes = [C.c_void_p]
         L.rt_buffer_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -158,6 +159,13 @@ class Scene:
                                            _ptr(out["front"], C.c_int32), _ptr(out["nbox"], C.c_uint32), _ptr(out["nleaf"], C.c_uint32),
                                            _ptr(out["hash"], C.c_uint64)))
         return out
+
+    def first_hit_fast(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        n = len(rays)
+        prim, t = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        _check(load_library().rt_first_hit_fast(self.h, _ptr(rays, C.c_double), n, _ptr(prim, C.c_int32), _ptr(t, C.c_float)))
+        return dict(prim=prim, t=t)
 
     def render(self, accum_ptr, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0,
                y_begin=0, y_end=None, stream=None, want_stats=True):

@@ -185,6 +185,11 @@ class Scene:
         lib().orc_primary_rays(self.h, side, _p(out, C.c_double))
         return out
 
+    def debug_path(self, i, j, k, seed, max_depth):
+        out = np.zeros((max_depth + 1, 7))
+        n = lib().orc_debug_path(self.h, i, j, k, C.c_uint64(seed), max_depth, _p(out, C.c_double), len(out))
+        return out[:n]
+
     def set_early_exit(self, on):
         lib().orc_set_early_exit(self.h, int(on))
 
