@@ -71,6 +71,9 @@ struct alignas(16) BNode {
 };
 #define RT_BVH_SENTINEL ((int32_t) 0x80000000)
 #define RT_BVH_STACK_MAX 64
+#ifndef RT_WAVES_FP32
+#define RT_WAVES_FP32 4   // waves per SIMD the fp32 render kernels are compiled for (<= 128 VGPRs)
+#endif
 
 // cold triangle record (shading only): vertex normals and uvs
 template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
@@ -689,7 +692,7 @@ struct RenderArgs {
 // path later misses (0 * inf); `poisoned` carries that.
 // kTrav: 0 reference-order program in global memory, 1 the same staged in LDS, 2 fast-mode SAH tree (fp32 only)
 template <typename R, int kTrav, bool kCount>
-__global__ void __launch_bounds__(256) render_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) render_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const Op<R>* ops = sc.ops;
