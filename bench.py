@@ -77,6 +77,7 @@ def main():
     import torch.distributed as dist
     import raytracing_amd as R
     from raytracing_amd.host_scenes import HostScene
+    from raytracing_amd.parallel import reduce_frame, sample_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,16 +110,14 @@ def main():
     os.close(saved_stdout)
 
     # this rank's share of the frame's samples
-    k0 = rank * spp // world
-    k1 = (rank + 1) * spp // world
+    k0, k1 = sample_range(rank, world, spp)
     accum = torch.zeros((h, w, 3), dtype=dtype, device="cuda")
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         st = scene.render(accum.data_ptr(), w, h, k0, k1, args.depth, mode, seed=1, stream=stream)   # syncs, returns kernel stats
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_frame(accum, world, dst=0)
         if rank == 0:
             R.resolve(accum.data_ptr(), args.mode == "fp64", w * h, spp, rgb.data_ptr(), stream=stream)
         return st
