@@ -49,26 +49,30 @@ def parse():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--mode", choices=["fp32", "fp32ref", "fp64"], default="fp32", help="fp32: fast SAH tree; fp32ref: reference tree in fp32; fp64: reference mode")
     ap.add_argument("--workload", choices=["random_spheres", "obj"], default="random_spheres")
-    ap.add_argument("--obj", default=os.path.join(ROOT, "tests", "golden", "mesh_scene.obj"))
+    ap.add_argument("--obj", default="auto", help="OBJ file of the obj workload; auto = generate the procedural mesh (raytracing_amd/tools/make_mesh.py)")
+    ap.add_argument("--mesh-level", type=int, default=8, help="icosphere subdivision of the generated mesh: 8 -> 1.31 M triangles")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=1)
     return ap.parse_args()
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, host_arrays):
     """Oracle (kind 'port': CPU restatement of the reference, pinned bit-exact to it by tests/golden) on the host cores.
-    Bounded sample: the same scene, resolution and depth at --cpu-spp samples per pixel."""
+    Bounded sample: the same scene (re-created from the host mirror's flattened arrays), resolution and depth at
+    --cpu-spp samples per pixel."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = min(16, os.cpu_count() or 1)
-    s = O.Scene.c0(args.width, args.height, 1)
+    # random_spheres: the oracle's own builder (nested bvh over shutter [0,1], as the reference builds it); OBJ: static
+    # triangles re-created from the flattened arrays
+    s = O.Scene.c0(args.width, args.height, 1) if args.workload == "random_spheres" else O.scene_from_arrays(host_arrays, 1)
     t0 = time.perf_counter()
     _, _, cnt = s.render(0, args.cpu_spp, args.depth, O.RNG_COUNTER, seed=1, n_threads=cores, want_rgb=False)
     dt = time.perf_counter() - t0
     s.free()
     return {"value": round(int(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"random_spheres {args.width}x{args.height}, {args.cpu_spp} spp, max_depth {args.depth}: "
-                      f"{int(cnt[0])} rays in {dt:.2f} s (fp64, OpenMP over rows, per-(pixel,sample) RNG streams)"}
+            "sample": f"{args.workload} {args.width}x{args.height}, {args.cpu_spp} spp, max_depth {args.depth}: "
+                      f"{int(cnt[0])} rays in {dt:.2f} s (fp64, reference tree, OpenMP over rows, per-(pixel,sample) RNG streams)"}
 
 
 def main():
@@ -103,8 +107,15 @@ def main():
         host = HostScene.random_spheres(w, h, 1)
         workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
     else:
-        host = HostScene.obj(args.obj, w, h, 1)
-        workload = f"OBJ scene {os.path.basename(args.obj)} through the loader, {w}x{h}, {spp} spp, max_depth {args.depth}"
+        obj_path = args.obj
+        if obj_path == "auto":
+            from raytracing_amd.tools.make_mesh import write_scene
+            obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_blob_l{args.mesh_level}_r{rank}.obj")
+            n_tri = write_scene(obj_path, args.mesh_level)
+        host = HostScene.obj(obj_path, w, h, 1, cam_pos=(0, 1.8, 5.0), cam_lookat=(0, 1.0, 0), fov=40.0)
+        n_tri = int(host.desc.contents.n_prims)
+        workload = (f"BASELINE configs[2]: procedural OBJ mesh ({n_tri} triangles, diffuse/specular MTL + emissive quad) through the OBJ loader "
+                    f"and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
     scene = host.upload()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
@@ -177,14 +188,14 @@ def main():
             "metric": "Mrays/s (node), path-traced frame; image RMSE vs reference CPU checked in tests/", "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.mode == "fp64" else "f32",
-            "data": "synthetic (procedural scene from the reference's random_scene(), rand() seed 1)",
+            "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
                        "parallelism": f"spp split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu and args.workload == "random_spheres":
-            out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, host.arrays())
         print(json.dumps(out), flush=True)
 
     scene.destroy()

@@ -782,6 +782,30 @@ int orc_add_triangle_p(orc_scene* s, const double p[9], int mat, int flip, int t
     double uv[6] = { p0.x, p0.y, p1.x, p1.y, p2.x, p2.y };
     return finish_add(s, mk_triangle(p, n, uv, mat), flip, to_lights);
 }
+/* bulk add from flattened records (layout of include/rtcore.h): used by bench.py's cpu_baseline leg to time the oracle
+ * on a scene the host mirror built.  Triangle corners are rebuilt as p0, p0+e1, p0+e2 (bounding boxes may differ from
+ * the loader's by an ulp: good enough for a timing baseline, not used by the parity tests). */
+void orc_add_prims_bulk(orc_scene* s, int n, const int32_t* kind, const int32_t* flags, const int32_t* mat, const double* data, int to_lights)
+{
+    for (int i = 0; i < n; i++) {
+        const double* g = data + (size_t) i * ORC_PRIM_STRIDE;
+        int fl = flags[i] & 1;
+        switch (kind[i]) {
+        case ORC_SPHERE: orc_add_sphere(s, g, g[3], mat[i], fl, to_lights); break;
+        case ORC_MSPHERE: orc_add_msphere(s, g, g + 3, g[6], g[7], g[8], mat[i], fl, to_lights); break;
+        case ORC_TRIANGLE: {
+            double p[9];
+            for (int k = 0; k < 3; k++) { p[k] = g[k]; p[3 + k] = g[k] + g[3 + k]; p[6 + k] = g[k] + g[6 + k]; }
+            orc_obj* o = mk_triangle(p, g + 9, g + 18, mat[i]);
+            for (int k = 0; k < 6; k++) o->g[3 + k] = g[3 + k];
+            finish_add(s, o, fl, to_lights);
+            break;
+        }
+        default: orc_add_plane(s, kind[i], g[0], g[1], g[2], g[3], g[4], mat[i], fl, to_lights); break;
+        }
+    }
+}
+
 int orc_add_light_alias(orc_scene* s, int prim_id)
 { push(&s->lights, &s->n_lights, &s->cap_lights, s->prims[prim_id]); return s->n_lights - 1; }
 
@@ -792,6 +816,13 @@ void orc_set_camera(orc_scene* s, const double pos[3], const double lookat[3], c
     s->fov = fov; s->aperture = aperture; s->focus = focus; s->shutter0 = shutter0; s->shutter1 = shutter1;
     s->aspect = (double) s->width / s->height;                           /* scene.hpp:57-62 overrides the user's aspect */
     setup_camera(s);
+}
+
+void orc_set_camera_fields(orc_scene* s, const double c[24])    /* derived fields as exported by orc_camera_fields */
+{
+    s->cam_pos = V(c[0], c[1], c[2]); s->left_bottom = V(c[3], c[4], c[5]); s->horizontal = V(c[6], c[7], c[8]); s->vertical = V(c[9], c[10], c[11]);
+    s->cu = V(c[12], c[13], c[14]); s->cv = V(c[15], c[16], c[17]); s->cw = V(c[18], c[19], c[20]);
+    s->lens_radius = c[21]; s->shutter0 = c[22]; s->shutter1 = c[23];
 }
 
 void orc_build_bvh(orc_scene* s)                                        /* scene.hpp:46-51: bvh(objects) with start=end=0 */

@@ -354,3 +354,54 @@ def obj_scene(path, width, height, seed):
     s.set_camera((0, 1.6, 4.2), (0, 0.6, 0), (0, 1, 0), 40, 0, 1, 0, 1)
     s.build_bvh()
     return s
+
+
+def scene_from_arrays(d, seed=1):
+    """Oracle scene from flattened arrays (raytracing_amd.host_scenes.HostScene.arrays()): textures, materials,
+    primitives and lights are re-created in array order, then the oracle builds ONE reference-semantics BVH over all
+    of them with time range (0,0) -- right for static scenes (OBJ); moving spheres need the nested bvh(.,0,1) of
+    random_scene, use Scene.c0 for that."""
+    s = Scene.new(int(d["width"]), int(d["height"]), seed)
+    tex_ids = {}
+
+    def tex(i):
+        if i in tex_ids:
+            return tex_ids[i]
+        k, t = int(d["tex_kind"][i]), d["tex_data"][i]
+        if k == 1:
+            tex_ids[i] = s.tex_constant(*t[:3])
+        elif k == 2:
+            tex_ids[i] = s.tex_checker(tex(int(t[0])), tex(int(t[1])))
+        else:
+            w, h, ch, off = int(t[0]), int(t[1]), int(t[2]), int(t[4])
+            tex_ids[i] = s.tex_image(d["tex_pixels"][off:off + w * h * ch].reshape(h, w, ch), t[3] != 0)
+        return tex_ids[i]
+
+    for i in range(len(d["tex_kind"])):
+        tex(i)
+    for i, k in enumerate(d["mat_kind"]):
+        m, t = d["mat_data"][i], int(d["mat_tex"][i])
+        t = tex_ids.get(t, -1)
+        if k == 1:
+            s.mat_lambertian(t)
+        elif k == 2:
+            s.mat_metal(t, m[0])
+        elif k == 3:
+            s.mat_dielectric(m[0])
+        elif k == 4:
+            s.mat_emissive(t)
+        else:
+            s.mat_phong(m[1:4], m[4:7], m[7:10], m[10:13], m[13], m[14], t)
+    I, D = C.c_int32, C.c_double
+    for pre, to_lights in (("prim", 0), ("light", 1)):
+        kind = np.ascontiguousarray(d[pre + "_kind"], np.int32)
+        flags = np.ascontiguousarray(d[pre + "_flags"], np.int32)
+        mat = np.ascontiguousarray(d[pre + "_mat"], np.int32)
+        data = np.ascontiguousarray(d[pre + "_data"], np.float64)
+        lib().orc_add_prims_bulk(s.h, len(kind), _p(kind, I), _p(flags, I), _p(mat, I), _p(data, D), to_lights)
+    cam = d["camera"]
+    # camera fields are already derived: set them through a look-at that reproduces them is not possible in general,
+    # so install them directly
+    lib().orc_set_camera_fields(s.h, _p(np.ascontiguousarray(cam, np.float64), D))
+    s.build_bvh()
+    return s
