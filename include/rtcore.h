@@ -110,6 +110,9 @@ typedef struct rt_render_stats {
     double kernel_ms;            /* HIP-event time of the render kernel on params.stream */
     uint64_t box_tests;          /* aabb::intersect calls (aabb.hpp:23-41), only with RT_FLAG_COUNT_TESTS */
     uint64_t leaf_tests;         /* primitive intersect calls, only with RT_FLAG_COUNT_TESTS */
+    uint64_t wave_node_steps;    /* RT_FLAG_COUNT_TESTS, fast mode: wave-level iterations of the node loop (x64 lanes = issue slots) */
+    uint64_t wave_leaf_steps;    /* ... of the leaf-test loop */
+    uint64_t wave_bounces;       /* ... of the bounce loop */
 } rt_render_stats;
 
 /* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit

@@ -158,6 +158,14 @@ template <typename R> __device__ inline vec3<R> random_cosine(Rng& g)          /
     R y = rt_sin(phi) * rt_sqrt(r2);
     return vec3<R>(x, y, z);
 }
+// fp32: phi = 2*pi*r1 with r1 in [0,1): the hardware sine/cosine take their argument in revolutions (v_sin_f32 / v_cos_f32),
+// so no range reduction and no 2*pi multiply are needed.
+template <> __device__ inline vec3<float> random_cosine<float>(Rng& g)
+{
+    float r1 = uniform<float>(g), r2 = uniform<float>(g);
+    float z = sqrtf(1.0f - r2), s = sqrtf(r2);
+    return vec3<float>(__builtin_amdgcn_cosf(r1) * s, __builtin_amdgcn_sinf(r1) * s, z);
+}
 template <typename R> __device__ inline vec3<R> reflect(const vec3<R>& in, const vec3<R>& n) { return in - (R(2) * dot(in, n)) * n; } // util.hpp:154-157
 template <typename R> __device__ inline vec3<R> refract(const vec3<R>& in, const vec3<R>& n, R ratio)                                  // util.hpp:160-166
 {
@@ -378,7 +386,8 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
     if (p.flags & RT_PRIM_FLAG_FLIP) h.front = !h.front;
 }
 
-struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; };
+struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; uint32_t w_node, w_leaf, w_bounce; };   // w_*: wave-level loop iterations (counted by the first active lane)
+__device__ inline bool first_active_lane() { return (int) __lane_id() == __ffsll((unsigned long long) __ballot(1)) - 1; }
 
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
 template <typename R, int kStats>   // 0: none, 1: count box/leaf tests, 2: counts + visit-order hash
@@ -441,6 +450,7 @@ __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Pri
     while (cur != RT_BVH_SENTINEL) {
         while (cur >= 0) {
             const BNode n = nodes[cur];
+            if (kStats && first_active_lane()) st->w_node++;
             float tl, tr; bool hl, hr;
             slab2(n.lb, r.o, idir, t_min, closest, tl, hl);
             slab2(n.rb, r.o, idir, t_min, closest, tr, hr);
@@ -460,6 +470,7 @@ __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Pri
         const int code = ~cur, first = code >> 3, count = (code & 7) + 1;
         for (int k = 0; k < count; k++) {
             float t;
+            if (kStats && first_active_lane()) st->w_leaf++;
             if (kStats) st->n_leaf++;
             if (prim_t(prims[first + k], r, t_min, closest, t)) { closest = t; hit = first + k; }
         }
@@ -678,6 +689,7 @@ struct RenderArgs {
     uint64_t seed;
     uint32_t lds_ops_bytes, lds_prims_bytes;   // 0: read the traversal program from global memory
     uint32_t bvh_stack_levels;                 // > 0: fast mode, LDS stack of this many dwords per lane
+    uint32_t lds_tile_offset;                  // fp32 modes: byte offset of the tile accumulation buffer (768 floats + counter) in LDS
 };
 
 // ------------------------------------------------------------------ render kernel
@@ -712,27 +724,63 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
 
     const int tiles_x = (a.width + 15) >> 4;
     const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int i = a.y_begin + tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool in_image = j < a.width && i < a.y_end;
+    const int lane = threadIdx.x & 63;
+    // pixel of slot `local` (0..255) of this workgroup's 16x16 tile: waves are 8x8 sub-tiles
+    auto pixel_of = [&](int local, int& jj, int& ii) {
+        const int wv = local >> 6, ln = local & 63;
+        jj = tile_x * 16 + (wv & 1) * 8 + (ln & 7);
+        ii = a.y_begin + tile_y * 16 + (wv >> 1) * 8 + (ln >> 3);
+    };
+
+    // Work distribution.  fp64 reference mode: a lane owns one pixel and walks its samples (deterministic sums, bit-identical
+    // under spp / row splits).  fp32 modes: the WORKGROUP owns the tile; lanes pull (sample, pixel) items from an LDS
+    // counter -- item = sample * 256 + slot, so a wave's simultaneous fetches are neighbouring pixels of one sample -- and
+    // add finished samples into an LDS tile buffer.  A pixel whose paths are 20x longer than its neighbours' (a glass
+    // sphere's silhouette) then no longer pins 63 idle lanes to its wave: measured bounce-level lane utilisation 0.59 -> ~1.
+    constexpr bool kDynamic = sizeof(R) == sizeof(float);
+    float* tile_sum = reinterpret_cast<float*>(smem + a.lds_tile_offset);
+    unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
+    if (kDynamic) {
+        tile_sum[threadIdx.x * 3] = 0.f; tile_sum[threadIdx.x * 3 + 1] = 0.f; tile_sum[threadIdx.x * 3 + 2] = 0.f;
+        if (threadIdx.x == 0) *item_counter = 0u;
+        __syncthreads();
+    }
+    const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
 
     unsigned long long n_rays = 0, n_rejected = 0;
-    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0;
+    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
     vec3<R> sum;
+    int i, j, local = threadIdx.x;
+    pixel_of(local, j, i);
+    const bool own_in_image = j < a.width && i < a.y_end;
 
-    if (in_image) {
-        const uint32_t pixel = (uint32_t) (i * a.width + j);
+    if (kDynamic || own_in_image) {
+        uint32_t pixel = (uint32_t) (i * a.width + j);
         int k = a.spp_begin;
         bool alive = false, poisoned = false;
-        int depth = 0;
+        int depth = 0, path_rays = 0;
         Rng g; g.s = 0;
         Ray<R> ray;
         vec3<R> beta, L;
 
         for (;;) {
             if (!alive) {
-                if (k >= a.spp_end) break;
+                if (kDynamic) {
+                    // one LDS atomic per wave: the first fetching lane reserves a run of items for all fetching lanes
+                    const unsigned long long need = __ballot(1);
+                    const int leader = __ffsll(need) - 1;
+                    unsigned int base = 0;
+                    if (lane == leader) base = atomicAdd(item_counter, (unsigned int) __popcll(need));
+                    base = __shfl(base, leader, 64);
+                    const unsigned int item = base + (unsigned int) __popcll(need & ((1ull << lane) - 1ull));
+                    if (item >= n_items) break;
+                    local = (int) (item & 255u);
+                    k = a.spp_begin + (int) (item >> 8);
+                    pixel_of(local, j, i);
+                    if (!(j < a.width && i < a.y_end)) continue;     // slot outside the image (edge tiles)
+                    pixel = (uint32_t) (i * a.width + j);
+                }
+                else if (k >= a.spp_end) break;
                 g.seed(a.seed, pixel, (uint32_t) k);
                 k++;
                 R x = (R(j) + uniform<R>(g)) / R(a.width - 1);                             // raytracing.cpp:102-103
@@ -742,12 +790,15 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
                 L = vec3<R>();
                 depth = a.max_depth;
                 poisoned = false;
+                path_rays = 0;
                 alive = depth > 0;
                 if (!alive) continue;
             }
 
             // ---- one path segment: trace() body for the current depth
             n_rays++;
+            path_rays++;
+            if (kCount && first_active_lane()) vs.w_bounce++;
             R t;
             int prim;
             if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs);
@@ -787,12 +838,27 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
                 alive = false;
                 bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
                 if (bad) n_rejected++;
-                else sum += L;
+                if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<R>(R(path_rays), bad ? R(1) : R(0), R(0)); bad = false; }
+                if (!bad) {
+                    if (kDynamic) {
+                        float* dst = tile_sum + local * 3;
+                        __hip_atomic_fetch_add(dst, (float) L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(dst + 1, (float) L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(dst + 2, (float) L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    else sum += L;
+                }
             }
         }
+    }
 
-        if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) sum = vec3<R>(R((double) n_rays), R((double) n_rejected), R(0));
-        R* out = accum + (size_t) pixel * 3;
+    if (kDynamic) {
+        __syncthreads();
+        sum = vec3<R>(R(tile_sum[threadIdx.x * 3]), R(tile_sum[threadIdx.x * 3 + 1]), R(tile_sum[threadIdx.x * 3 + 2]));
+        pixel_of((int) threadIdx.x, j, i);
+    }
+    if (own_in_image) {
+        R* out = accum + ((size_t) i * a.width + j) * 3;
         if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sum.x; out[1] += sum.y; out[2] += sum.z; }
         else { out[0] = sum.x; out[1] = sum.y; out[2] = sum.z; }
     }
@@ -808,10 +874,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
         if (n_rejected) atomicAdd(&counters[1], n_rejected);
     }
     if (kCount) {   // diagnostic launches only: per-lane 32-bit counts are ample for one launch's per-pixel work
-        unsigned long long nb = vs.n_box, nl = vs.n_leaf;
+        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64); }
-        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); }
+        for (int off = 32; off > 0; off >>= 1) {
+            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64);
+            wn += __shfl_down(wn, off, 64); wl += __shfl_down(wl, off, 64); wb += __shfl_down(wb, off, 64);
+        }
+        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); }
     }
 }
 
@@ -827,7 +896,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
     r.o = vec3<R>(R(p[0]), R(p[1]), R(p[2]));
     r.d = vec3<R>(R(p[3]), R(p[4]), R(p[5]));
     r.time = R(p[6]);
-    VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL;
+    VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL; st.w_node = st.w_leaf = st.w_bounce = 0;
     R t;
     int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, r, t, &st);
     prim[idx] = hit;

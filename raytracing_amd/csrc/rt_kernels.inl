@@ -3,38 +3,50 @@
 
 namespace rt {
 
-hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a, RT_REAL* accum, unsigned long long* counters, hipStream_t s)
+hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_REAL* accum, unsigned long long* counters, hipStream_t s)
 {
+    RenderArgs a = a_in;
     const int tiles_x = (a.width + 15) / 16, tiles_y = (a.y_end - a.y_begin + 15) / 16;
     if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
     dim3 grid((unsigned) (tiles_x * tiles_y)), block(256);
-    const size_t lds = (size_t) a.lds_ops_bytes + a.lds_prims_bytes;
     const bool count = (a.flags & RT_FLAG_COUNT_TESTS) != 0;
+    // dynamic LDS = [traversal region: fast-mode stack | staged program | nothing] + [fp32 modes: tile sums + item counter]
+    const size_t tile_bytes = sizeof(RT_REAL) == sizeof(float) ? 768 * sizeof(float) + 16 : 0;
+    size_t region = 0;
+    int trav = 0;
 #ifdef RT_WITH_FAST_BVH
-    if (a.bvh_stack_levels > 0) {
-        const size_t stack_bytes = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t);
-        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 2, true>), grid, block, stack_bytes, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_kernel<RT_REAL, 2, false>), grid, block, stack_bytes, s, sc, a, accum, counters);
-        return hipGetLastError();
-    }
+    if (a.bvh_stack_levels > 0) { trav = 2; region = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t); }
 #endif
-    if (lds > 0) {
+    if (trav == 0 && a.lds_ops_bytes + a.lds_prims_bytes > 0) { trav = 1; region = (size_t) a.lds_ops_bytes + a.lds_prims_bytes; }
+    a.lds_tile_offset = (uint32_t) region;
+    const size_t lds = region + tile_bytes;
+    if (lds > 48 * 1024) {
         static thread_local size_t configured = 0;
         if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+#ifdef RT_WITH_FAST_BVH
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+#endif
             if (e != hipSuccess) return e;
             configured = lds;
         }
+    }
+#ifdef RT_WITH_FAST_BVH
+    if (trav == 2) {
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 2, true>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, 2, false>), grid, block, lds, s, sc, a, accum, counters);
+        return hipGetLastError();
+    }
+#endif
+    if (trav == 1) {
         if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 1, true>), grid, block, lds, s, sc, a, accum, counters);
         else hipLaunchKernelGGL((render_kernel<RT_REAL, 1, false>), grid, block, lds, s, sc, a, accum, counters);
     }
     else {
-        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 0, true>), grid, block, 0, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_kernel<RT_REAL, 0, false>), grid, block, 0, s, sc, a, accum, counters);
+        if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 0, true>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_kernel<RT_REAL, 0, false>), grid, block, lds, s, sc, a, accum, counters);
     }
     return hipGetLastError();
 }

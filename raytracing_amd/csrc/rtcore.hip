@@ -362,7 +362,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (e != hipSuccess) { delete s; return fail(RT_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e) + " (no HIP device: the HIP path is the only path)"); }
     if ((rc = build_device<double>(desc, f, s->d64)) || (rc = build_device<float>(desc, f, s->d32))) { rt_scene_destroy(s); return rc; }
     s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
-    if (hipMalloc((void**) &s->counters, 4 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
+    if (hipMalloc((void**) &s->counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
     if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
     *scene_out = s;
@@ -395,7 +395,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
-    HIP_TRY(hipMemsetAsync(s->counters, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->mode == RT_MODE_REFERENCE_FP64) {
         if ((size_t) s->d64.ops_bytes + s->d64.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d64.ops_bytes; a.lds_prims_bytes = s->d64.prims_bytes; }
@@ -411,9 +411,9 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         HIP_TRY(hipEventSynchronize(s->ev1));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-        unsigned long long c[4];
+        unsigned long long c[8];
         HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
-        stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3];
+        stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
     }
     return RT_OK;
 }
