@@ -244,7 +244,9 @@ static v3 tex_color(const orc_scene* s, int ti, v3 p, v2 uv)
         double u = uv.u < 0 ? 0 : (uv.u > 1 ? 1 : uv.u);
         double vv = uv.v < 0 ? 0 : (uv.v > 1 ? 1 : uv.v);
         double v = 1.0 - vv;
-        int x = (int) (u * w), y = (int) (v * h);
+        /* a NaN uv (acos of a sphere normal component a rounding error beyond 1, primitive.hpp:69) makes the reference
+         * index out of bounds (undefined behaviour); here, as on the GPU (v_cvt_i32_f32 of NaN is 0), it reads texel 0 */
+        int x = isnan(u) ? 0 : (int) (u * w), y = isnan(v) ? 0 : (int) (v * h);
         if (x >= w) x = w - 1;
         if (y >= h) y = h - 1;
         const double scale = 1.0 / 255;
@@ -823,6 +825,14 @@ void orc_set_camera_fields(orc_scene* s, const double c[24])    /* derived field
     s->cam_pos = V(c[0], c[1], c[2]); s->left_bottom = V(c[3], c[4], c[5]); s->horizontal = V(c[6], c[7], c[8]); s->vertical = V(c[9], c[10], c[11]);
     s->cu = V(c[12], c[13], c[14]); s->cv = V(c[15], c[16], c[17]); s->cw = V(c[18], c[19], c[20]);
     s->lens_radius = c[21]; s->shutter0 = c[22]; s->shutter1 = c[23];
+}
+
+void orc_build_bvh_range(orc_scene* s, double start, double end)          /* bvh(grp, start, end) as demo.hpp:58 */
+{
+    orc_obj* root = bvh_build(&s->rng, s->objects, 0, s->n_objects, start, end);
+    s->objects[0] = root;
+    s->n_objects = 1;
+    fix_pixels(s);
 }
 
 void orc_build_bvh(orc_scene* s)                                        /* scene.hpp:46-51: bvh(objects) with start=end=0 */

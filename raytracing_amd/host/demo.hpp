@@ -44,3 +44,28 @@ inline group random_scene()
     grp.add(new sphere(vec3d(4, 1, 0), 1.0, new metal(vec3d(0.7, 0.6, 0.5), 0)));
     return group(new bvh(grp, 0, 1));
 }
+
+// BASELINE config 4 ("dielectric/metal-heavy deep-bounce scene"): random_scene's layout with the small spheres' materials
+// remapped to 50 % dielectric, 40 % mirror metal (roughness 0), 10 % lambertian.  Not in the reference (its demo.hpp has
+// no such scene): defined by SURVEY 8d to stress wave divergence with long specular chains (max_depth 200).
+inline group deep_bounce_scene()
+{
+    group grp;
+    grp.add(new sphere(vec3d(0, -1000, 0), 1000, new lambertian(new checker(vec3d(0.1, 0.1, 0.1), vec3d(0.9, 0.9, 0.9)))));
+    for (int i = -11; i < 11; i++) {
+        for (int j = -11; j < 11; j++) {
+            double choose = random_double();
+            double cz = j + 0.9 * random_double();
+            double cx = i + 0.9 * random_double();
+            vec3d center(cx, 0.2, cz);
+            if ((center - vec3d(4, 0.2, 0)).length() <= 0.9) continue;
+            if (choose < 0.5) grp.add(new sphere(center, 0.2, new dielectric(1.5)));
+            else if (choose < 0.9) grp.add(new sphere(center, 0.2, new metal(random_vector(0.5, 1), 0)));
+            else grp.add(new sphere(center, 0.2, new lambertian(random_vector() * random_vector())));
+        }
+    }
+    grp.add(new sphere(vec3d(0, 1, 0), 1.0, new dielectric(1.5)));
+    grp.add(new sphere(vec3d(-4, 1, 0), 1.0, new metal(vec3d(0.9, 0.9, 0.9), 0)));
+    grp.add(new sphere(vec3d(4, 1, 0), 1.0, new metal(vec3d(0.7, 0.6, 0.5), 0)));
+    return group(new bvh(grp, 0, 1));
+}

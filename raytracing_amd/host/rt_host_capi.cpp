@@ -98,6 +98,55 @@ rth_scene* rth_build_mixed(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// BASELINE config 4: deep_bounce_scene() (demo.hpp) under the same light and camera as the random-spheres configs
+rth_scene* rth_build_deep_bounce(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        scn.add_object(deep_bounce_scene());
+        scn.add_object(new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4)))));
+        scn.add_light(new flip(new planexz(-20, 20, -20, 20, 30, new emissive(vec3d(4, 4, 4)))));
+        scn.set_camera(camera(vec3d(13, 2, 3), vec3d(0, 0, 0), vec3d(0, 1, 0), 20, double(width) / height, 0.1, 10, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+// image textures (texture.hpp:78-133) on a sphere (uv from the normal), on a lambertian triangle and as a phong map_Kd
+// (color_based = true: pow(., 2.2) per fetch), over a checker floor; texels are procedural
+rth_scene* rth_build_textured(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        std::vector<unsigned char> px(64 * 32 * 3), px4(16 * 16 * 4);
+        for (int y = 0; y < 32; y++) for (int x = 0; x < 64; x++) {
+            unsigned char* p = &px[(y * 64 + x) * 3];
+            p[0] = (unsigned char) (x * 4); p[1] = (unsigned char) (y * 8); p[2] = (unsigned char) (((x / 8 + y / 8) & 1) ? 220 : 40);
+        }
+        for (int i = 0; i < 16 * 16; i++) { px4[i * 4] = (unsigned char) (i); px4[i * 4 + 1] = (unsigned char) (255 - i); px4[i * 4 + 2] = (unsigned char) ((i * 7) & 255); px4[i * 4 + 3] = 255; }
+        scene scn(width, height);
+        group grp;
+        grp.add(new sphere(vec3d(0, -100.5, -1), 100, new lambertian(new checker(vec3d(0.2, 0.3, 0.1), vec3d(0.9, 0.9, 0.9)))));
+        grp.add(new sphere(vec3d(-0.6, 0.1, -1), 0.6, new lambertian(new image(px.data(), 64, 32, 3, false))));
+        grp.add(new msphere(vec3d(0.9, 0.0, -0.6), vec3d(0.9, 0.2, -0.6), 0, 1, 0.35, new metal(new image(px4.data(), 16, 16, 4, true), 0.2)));
+        vertex v[3];
+        v[0].position = vec3d(-1.8, -0.5, -2.2); v[1].position = vec3d(1.8, -0.5, -2.2); v[2].position = vec3d(0, 1.9, -2.4);
+        v[0].uv_coord = vec2d(-0.2, 0.0); v[1].uv_coord = vec2d(1.2, 0.0); v[2].uv_coord = vec2d(0.5, 1.1);     // outside [0,1]: exercises the clamp
+        for (int k = 0; k < 3; k++) v[k].normal = vec3d(0, 0.1, 1);
+        phong* mapped = new phong(new image(px.data(), 64, 32, 3, true));
+        grp.add(new triangle(v, mapped));
+        grp.add(new flip(new planexz(-1.5, 1.5, -2.5, 0.5, 3, new emissive(vec3d(5, 5, 5)))));
+        scn.add_object(grp);
+        scn.add_light(new flip(new planexz(-1.5, 1.5, -2.5, 0.5, 3, new emissive(vec3d(5, 5, 5)))));
+        scn.set_camera(camera(vec3d(0, 0.8, 3.2), vec3d(0, 0.3, -1), vec3d(0, 1, 0), 42, double(width) / height, 0.02, 4.0, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
 const rt_scene_desc* rth_desc(const rth_scene* s) { return s ? &s->desc : nullptr; }
 void rth_free(rth_scene* s) { delete s; }
 

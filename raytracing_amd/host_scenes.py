@@ -25,8 +25,9 @@ def load_host_library():
         L.rth_last_error.restype = C.c_char_p
         L.rth_build_random_spheres.restype = C.c_void_p
         L.rth_build_random_spheres.argtypes = [C.c_int, C.c_int, C.c_uint]
-        L.rth_build_mixed.restype = C.c_void_p
-        L.rth_build_mixed.argtypes = [C.c_int, C.c_int, C.c_uint]
+        for name in ("rth_build_mixed", "rth_build_deep_bounce", "rth_build_textured"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         L.rth_build_obj.restype = C.c_void_p
         L.rth_build_obj.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
         L.rth_desc.restype = C.POINTER(SceneDesc)
@@ -53,6 +54,14 @@ class HostScene:
     @classmethod
     def mixed(cls, width, height, seed=1):
         return cls(load_host_library().rth_build_mixed(width, height, seed), width, height)
+
+    @classmethod
+    def deep_bounce(cls, width, height, seed=1):
+        return cls(load_host_library().rth_build_deep_bounce(width, height, seed), width, height)
+
+    @classmethod
+    def textured(cls, width, height, seed=1):
+        return cls(load_host_library().rth_build_textured(width, height, seed), width, height)
 
     @classmethod
     def obj(cls, path, width, height, seed=1, cam_pos=(0, 1.6, 4.2), cam_lookat=(0, 0.6, 0), fov=40.0):

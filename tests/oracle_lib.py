@@ -117,8 +117,11 @@ class Scene:
     def set_camera(self, pos, lookat, up, fov, aperture, focus, s0, s1):
         lib().orc_set_camera(self.h, _d3(pos), _d3(lookat), _d3(up), *[C.c_double(x) for x in (fov, aperture, focus, s0, s1)])
 
-    def build_bvh(self):
-        lib().orc_build_bvh(self.h)
+    def build_bvh(self, t0=None, t1=None):
+        if t0 is None:
+            lib().orc_build_bvh(self.h)
+        else:
+            lib().orc_build_bvh_range(self.h, C.c_double(t0), C.c_double(t1))
 
     # ---- dumps
     def tree_rows(self):
@@ -359,8 +362,7 @@ def obj_scene(path, width, height, seed):
 def scene_from_arrays(d, seed=1):
     """Oracle scene from flattened arrays (raytracing_amd.host_scenes.HostScene.arrays()): textures, materials,
     primitives and lights are re-created in array order, then the oracle builds ONE reference-semantics BVH over all
-    of them with time range (0,0) -- right for static scenes (OBJ); moving spheres need the nested bvh(.,0,1) of
-    random_scene, use Scene.c0 for that."""
+    of them with node boxes over the camera's shutter interval (closest hits do not depend on the tree shape)."""
     s = Scene.new(int(d["width"]), int(d["height"]), seed)
     tex_ids = {}
 
@@ -403,5 +405,5 @@ def scene_from_arrays(d, seed=1):
     # camera fields are already derived: set them through a look-at that reproduces them is not possible in general,
     # so install them directly
     lib().orc_set_camera_fields(s.h, _p(np.ascontiguousarray(cam, np.float64), D))
-    s.build_bvh()
+    s.build_bvh(float(cam[22]), float(cam[23]))     # node boxes over the camera shutter, so moving spheres stay inside them
     return s

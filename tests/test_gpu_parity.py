@@ -136,6 +136,35 @@ def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name
     osc.free()
 
 
+@pytest.mark.parametrize("which,depth", [("textured", 16), ("deep_bounce", 200)])
+def test_host_built_scenes_fp64_and_fp32_vs_oracle(R, which, depth):
+    """Scenes outside the reference's demos, built by the C++ host mirror (the product's scene path) and re-created for
+    the oracle from the flattened arrays: image textures (sphere uv, clamped triangle uv, color_based pow 2.2, RGBA) and the
+    BASELINE config-4 deep-bounce scene at max_depth 200.  Same bars as the fixture scenes."""
+    from raytracing_amd.host_scenes import HostScene
+    w, h, spp = 72, 48, 8
+    hs = getattr(HostScene, which)(w, h, 3)
+    osc = O.scene_from_arrays(hs.arrays(), 3)
+    want, want_rgb, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=21, n_threads=8)
+    sc = hs.upload()
+    got, rgb, st = sc.render_to_host(w, h, 0, spp, depth, R.MODE_REFERENCE_FP64, seed=21)
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert float((rel.max(axis=2) > 1e-9).mean()) < 0.02
+    assert abs(st["rays"] - int(cnt[0])) <= 0.005 * int(cnt[0]) + 8
+    # fp32 modes are compared with early exit on both sides: phong-on-sphere garbage rays (zero direction, NaN roots) are
+    # not imitated by the fp32 sphere test, see test_render_fp32_within_rmse_tolerance
+    osc.set_early_exit(1)
+    want_e, _, cnt_e = osc.render(0, spp, depth, O.RNG_COUNTER, seed=21, n_threads=8)
+    for mode in (R.MODE_FAST_FP32, R.MODE_FP32_REFERENCE_TREE):
+        got32, rgb32, st32 = sc.render_to_host(w, h, 0, spp, depth, mode, seed=21, flags=R.FLAG_EARLY_EXIT)
+        rmse = float(np.sqrt(np.mean((got32 - want_e) ** 2)) / max(np.sqrt(np.mean(want_e ** 2)), 1e-12))
+        assert rmse < 0.08, (mode, rmse)
+        assert abs(st32["rays"] - int(cnt_e[0])) <= 0.02 * int(cnt_e[0]), (mode, st32["rays"], int(cnt_e[0]))
+    sc.destroy()
+    osc.free()
+    hs.free()
+
+
 def test_resolve_matches_oracle(R):
     rng = np.random.default_rng(3)
     sums = np.concatenate([rng.uniform(0, 40, 3000), [0.0, 1e-9, 16.0, 15.999999, 1e9, 5e-324]]).reshape(-1, 3)
