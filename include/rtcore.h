@@ -92,6 +92,10 @@ typedef struct rt_scene_desc {
 
 #define RT_FLAG_COUNT_TESTS 4    /* diagnostic: also count box and leaf tests (slower kernel variant); fills stats.box_tests / leaf_tests */
 #define RT_FLAG_DEBUG_RAY_COUNTS 8 /* diagnostic: accum_dev receives per-pixel (rays, rejected samples, 0) instead of radiance sums */
+#define RT_FLAG_LEGACY_LOOP 16   /* diagnostic (A/B): RT_MODE_FAST_FP32 with the lane-synchronous bounce loop (every lane traverses to completion,
+                                    then every lane shades) instead of the per-wave traverse / shade / regenerate state machine */
+#define RT_FLAG_WAVEFRONT 32     /* RT_MODE_FAST_FP32 as a multi-kernel wavefront pipeline over a path pool in HBM (rt_wavefront.h) instead of
+                                    one kernel; blocks until the samples are done.  Slower than the default on the measured workloads. */
 
 typedef struct rt_render_params {
     int32_t width, height;       /* image size: pixel (j,i) -> sample position as raytracing.cpp:102-103 */
@@ -123,8 +127,10 @@ int rt_scene_destroy(rt_scene* scene);
 /* Renders samples [spp_begin, spp_end) of rows [y_begin, y_end): per pixel the SUM over those samples of
  * trace(emit(x, y)) with rejected samples zeroed -- the body of the k-loop at raytracing.cpp:101-113.
  * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
- * double for RT_MODE_REFERENCE_FP64, float for RT_MODE_FAST_FP32.  Asynchronous on params->stream unless
- * `stats` is non-NULL, in which case it synchronises the stream and fills *stats. */
+ * double for RT_MODE_REFERENCE_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
+ * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats.  With RT_FLAG_WAVEFRONT the call
+ * runs a loop of extend / shade kernels over a path pool (84 B per slot, RT_WF_SLOTS slots, default 2 Mi; allocated on the
+ * scene's first such call, freed by rt_scene_destroy), polls a device flag and returns when the samples are done. */
 int rt_render(rt_scene* scene, const rt_render_params* params, void* accum_dev, rt_render_stats* stats);
 
 /* mean, gamma 0.45, clamp, truncate to 8 bit: raytracing.cpp:115-121.  rgb_dev: n_pixels*3 bytes. */

@@ -690,6 +690,10 @@ struct RenderArgs {
     uint32_t lds_ops_bytes, lds_prims_bytes;   // 0: read the traversal program from global memory
     uint32_t bvh_stack_levels;                 // > 0: fast mode, LDS stack of this many dwords per lane
     uint32_t lds_tile_offset;                  // fp32 modes: byte offset of the tile accumulation buffer (768 floats + counter) in LDS
+    // rt_wave.h phase thresholds, in 1/256ths: stay in the traversal phase while traversing lanes >= trav_keep/256 of the
+    // lanes holding paths; stay in the node loop while lanes on inner nodes >= node_keep/256 of the traversing lanes;
+    // regenerate when at least regen_min lanes have no path (or none has one)
+    uint32_t trav_keep, node_keep, regen_min;
 };
 
 // ------------------------------------------------------------------ render kernel

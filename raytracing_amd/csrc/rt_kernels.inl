@@ -1,5 +1,11 @@
 // raytracing_amd/csrc/rt_kernels.inl -- launcher bodies, included with RT_REAL defined.
+#include <algorithm>
+#include <cstddef>
+#include <vector>
 #include "rt_launch.h"
+#ifdef RT_WITH_FAST_BVH
+#include "rt_wave.h"
+#endif
 
 namespace rt {
 
@@ -28,12 +34,19 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 #ifdef RT_WITH_FAST_BVH
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
             configured = lds;
         }
     }
 #ifdef RT_WITH_FAST_BVH
+    if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
+        if (count) hipLaunchKernelGGL((render_wave_kernel<true>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_wave_kernel<false>), grid, block, lds, s, sc, a, accum, counters);
+        return hipGetLastError();
+    }
     if (trav == 2) {
         if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 2, true>), grid, block, lds, s, sc, a, accum, counters);
         else hipLaunchKernelGGL((render_kernel<RT_REAL, 2, false>), grid, block, lds, s, sc, a, accum, counters);
@@ -52,6 +65,89 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 }
 
 #ifdef RT_WITH_FAST_BVH
+hipError_t wf_extend_grid(int lds_levels, int* grid_out)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wf_extend_kernel<false, false>), 256, (size_t) lds_levels * 1024);
+    if (e != hipSuccess) return e;
+    *grid_out = std::max(1, cus) * std::max(1, per_cu);
+    return hipSuccess;
+}
+
+hipError_t wf_render(const Scene<float>& sc, const RenderArgs& a_in, const WfBuffers& buf, float* accum, unsigned long long out[8], hipStream_t s)
+{
+    RenderArgs a = a_in;
+    WfPool p = buf.pool;
+    const bool count = (a.flags & RT_FLAG_COUNT_TESTS) != 0;
+    const uint32_t tiles_x = (uint32_t) (a.width + 7) / 8, tiles_y = (uint32_t) (a.y_end - a.y_begin + 7) / 8;
+    const int samples = a_in.spp_end - a_in.spp_begin;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    hipError_t e = hipMemsetAsync(p.ctl, 0, sizeof(WfCtl), s);
+    if (e != hipSuccess) return e;
+    if (!(a.flags & RT_FLAG_ACCUMULATE) && a.y_end > a.y_begin) {
+        e = hipMemsetAsync(accum + (size_t) a.y_begin * a.width * 3, 0, (size_t) (a.y_end - a.y_begin) * a.width * 3 * sizeof(float), s);
+        if (e != hipSuccess) return e;
+    }
+    unsigned int* host = static_cast<unsigned int*>(buf.host_pinned);
+    std::vector<unsigned long long> partial;
+    if (tiles_x && tiles_y && samples > 0 && a.max_depth > 0) {
+        p.tiles_x = tiles_x;
+        p.n_pix_padded = tiles_x * tiles_y * 64u;
+        const int per_pass = (int) std::max<uint64_t>(1, (1ull << 31) / p.n_pix_padded);     // items of one pass fit 31 bits
+        const size_t lds = (size_t) p.lds_levels * 1024;
+        const unsigned grid_e = p.extend_threads / 256;
+        const bool spill = buf.bvh_depth + 2 > (int) p.lds_levels;
+        for (int k0 = a_in.spp_begin; k0 < a_in.spp_end; k0 += per_pass) {
+            a.spp_begin = k0;
+            a.spp_end = std::min(a_in.spp_end, k0 + per_pass);
+            p.n_items = (uint32_t) (a.spp_end - a.spp_begin) * p.n_pix_padded;
+            p.n_slots = (uint32_t) std::min<uint64_t>(buf.capacity, ((uint64_t) p.n_items + 255) / 256 * 256);
+            p.region_slots = ((p.n_slots + RT_WF_CURSORS - 1) / RT_WF_CURSORS + RT_WF_CHUNK - 1) / RT_WF_CHUNK * RT_WF_CHUNK;
+            e = hipMemsetAsync(p.ctl, 0, offsetof(WfCtl, n_box), s);                           // flag and cursors; the diagnostic counters run on
+            if (e != hipSuccess) return e;
+            const unsigned grid_s = p.n_slots / 256;
+            hipLaunchKernelGGL(wf_generate_kernel, dim3(grid_s), dim3(256), 0, s, sc, p, a);
+            // greedy scheduling bound: every iteration extends every live slot by one segment, a sample has <= max_depth of them
+            const uint64_t max_iters = ((uint64_t) p.n_items / p.n_slots + 2) * (uint64_t) a.max_depth + 64;
+            // a slot renders n_items / n_slots samples one after the other, each at least one segment long
+            uint64_t iters = 0, batch = std::min<uint64_t>(std::max<uint64_t>(4, (uint64_t) p.n_items / p.n_slots), 64);
+            for (;;) {
+                for (uint64_t b = 0; b < batch; b++) {
+                    if (count) {
+                        if (spill) hipLaunchKernelGGL((wf_extend_kernel<true, true>), dim3(grid_e), dim3(256), lds, s, sc, p, a);
+                        else hipLaunchKernelGGL((wf_extend_kernel<true, false>), dim3(grid_e), dim3(256), lds, s, sc, p, a);
+                        hipLaunchKernelGGL((wf_shade_kernel<true>), dim3(grid_s), dim3(256), 0, s, sc, p, a, accum);
+                    }
+                    else {
+                        if (spill) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(grid_e), dim3(256), lds, s, sc, p, a);
+                        else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(grid_e), dim3(256), lds, s, sc, p, a);
+                        hipLaunchKernelGGL((wf_shade_kernel<false>), dim3(grid_s), dim3(256), 0, s, sc, p, a, accum);
+                    }
+                }
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if ((e = hipMemcpyAsync(host, p.ctl, sizeof(unsigned int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+                if (host[0] == 0) break;                                                       // no slot holds a path any more
+                if ((iters += batch) > max_iters) return hipErrorLaunchFailure;                // cannot happen: the pool failed to drain
+                batch = std::min<uint64_t>(batch, 16);
+            }
+            partial.resize((size_t) grid_s * 2);
+            if ((e = hipMemcpy(partial.data(), p.wg_rays, (size_t) grid_s * 8, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            if ((e = hipMemcpy(partial.data() + grid_s, p.wg_rejected, (size_t) grid_s * 8, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            for (unsigned i = 0; i < grid_s; i++) { out[0] += partial[i]; out[1] += partial[grid_s + i]; }
+        }
+    }
+    if (count) {
+        if ((e = hipMemcpyAsync(host, p.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        const WfCtl* c = static_cast<const WfCtl*>(buf.host_pinned);
+        out[2] = c->n_box; out[3] = c->n_leaf; out[4] = c->w_node; out[5] = c->w_leaf; out[6] = c->w_bounce;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int n, int32_t* prim, float* t, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;

@@ -3,10 +3,16 @@
 // rt_kernels_fp32.hip with the default contraction.
 #pragma once
 #include "rt_device.h"
+#include "rt_wavefront.h"
 
 namespace rt {
 hipError_t launch_render(const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, hipStream_t s);
 hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* accum, unsigned long long* counters, hipStream_t s);
+// RT_MODE_FAST_FP32: wavefront loop over a path pool (rt_wavefront.h).  Blocks until the frame's samples are done; fills
+// out[0..6] = rays, rejected samples, box tests, leaf tests, wave node steps, wave leaf steps, shade waves.
+struct WfBuffers { WfPool pool; uint32_t capacity; int bvh_depth; void* host_pinned; };
+hipError_t wf_extend_grid(int lds_levels, int* grid_out);
+hipError_t wf_render(const Scene<float>& sc, const RenderArgs& a, const WfBuffers& buf, float* accum, unsigned long long out[8], hipStream_t s);
 hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int n, int32_t* prim, float* t, hipStream_t s);
 hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,
                             uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash, hipStream_t s);

@@ -1,0 +1,252 @@
+// raytracing_amd/csrc/rt_wave.h -- RT_MODE_FAST_FP32 render kernel: a per-wavefront state machine.
+//
+// Replaces, for the fast mode, the lane-synchronous bounce loop of rt_device.h (one traversal to completion for all
+// 64 lanes, then one shading pass).  Measured on that loop (profiles/, tools/lane_efficiency.py): the traversal ran at
+// 25-31 % lane utilisation, because a wave's traversal lasts as long as its slowest ray (4x the mean node count on the
+// mesh workload) while the kernel is VALU-issue bound.  Here every lane carries an explicit state
+//     no path  ->  traversing (cur != sentinel)  ->  hit known (cur == sentinel)  ->  traversing | no path
+// and the wave alternates between three wave-uniform phases, each entered only when enough lanes want it:
+//   regenerate : lanes without a path pull (sample, pixel) items from the workgroup's LDS counter and emit camera rays;
+//   traverse   : lanes step through the SAH tree; the phase is left as soon as fewer than `trav_keep`/256 of the lanes
+//                holding paths are still traversing -- their traversal state (node, stack pointer, closest hit) simply
+//                stays in registers / LDS and resumes on the next round;
+//   shade      : lanes whose closest hit is known run the trace() body (raytracing.cpp:41-69) and either start the
+//                next segment's traversal or retire the sample into the LDS tile.
+// Same arithmetic, RNG streams and sample sums as the loop it replaces (order of the fp32 tile additions aside).
+#pragma once
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct Trav {                 // per-lane traversal state, kept across phases
+    vec3<float> idir, noid;   // 1/d and -o/d: a slab plane distance is one fma
+    float slack;              // absolute slack of the slab comparison (rounding of o/d)
+    float closest;
+    int32_t hit, cur, sp;
+};
+
+__device__ inline void trav_begin(Trav& t, const Ray<float>& r)
+{
+    // a zero direction component would make 0 * inf = NaN in the slab test: nudge it (box tests only)
+    auto safe = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; };
+    t.idir = vec3<float>(1.0f / safe(r.d.x), 1.0f / safe(r.d.y), 1.0f / safe(r.d.z));
+    t.noid = vec3<float>(-r.o.x * t.idir.x, -r.o.y * t.idir.y, -r.o.z * t.idir.z);
+    // t = fma(plane, idir, -o*idir) rounds once; what is left is the rounding of o*idir itself (<= 1/2 ulp of it)
+    t.slack = 2.4e-7f * fmaxf(fmaxf(fabsf(t.noid.x), fabsf(t.noid.y)), fabsf(t.noid.z));
+    t.closest = rt_inf<float>();
+    t.hit = -1;
+    t.cur = 0;
+    t.sp = 0;
+}
+
+__device__ inline void slab_fma(const float* b, const Trav& t, float t_min, float& t_near, bool& hit)
+{
+    float x0 = fmaf(b[0], t.idir.x, t.noid.x), x1 = fmaf(b[3], t.idir.x, t.noid.x);
+    float y0 = fmaf(b[1], t.idir.y, t.noid.y), y1 = fmaf(b[4], t.idir.y, t.noid.y);
+    float z0 = fmaf(b[2], t.idir.z, t.noid.z), z1 = fmaf(b[5], t.idir.z, t.noid.z);
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t.closest));
+    t_near = tn;
+    hit = tn <= fmaf(tf, 1.0000004f, t.slack);     // conservative under fp32 rounding
+}
+
+template <bool kCount>
+__global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
+                                                                         unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;       // entry `level` of this lane: stack[level * 256]
+    float* tile_sum = reinterpret_cast<float*>(smem + a.lds_tile_offset);
+    unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
+    tile_sum[threadIdx.x * 3] = 0.f; tile_sum[threadIdx.x * 3 + 1] = 0.f; tile_sum[threadIdx.x * 3 + 2] = 0.f;
+    if (threadIdx.x == 0) *item_counter = 0u;
+    stack[0] = (uint32_t) RT_BVH_SENTINEL;
+    __syncthreads();
+
+    const int tiles_x = (a.width + 15) >> 4;
+    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const int lane = threadIdx.x & 63;
+    auto pixel_of = [&](int local, int& jj, int& ii) {       // slot 0..255 of the 16x16 tile: waves are 8x8 sub-tiles
+        const int wv = local >> 6, ln = local & 63;
+        jj = tile_x * 16 + (wv & 1) * 8 + (ln & 7);
+        ii = a.y_begin + tile_y * 16 + (wv >> 1) * 8 + (ln >> 3);
+    };
+    const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
+    const float t_min = consts<float>::tmin;
+    const BNode* __restrict__ nodes = sc.bnodes;
+    const Prim<float>* __restrict__ fprims = sc.fprims;
+    const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
+
+    unsigned long long n_rays = 0, n_rejected = 0;
+    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
+
+    bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
+    int depth = 0, path_rays = 0, local = 0;
+    Rng g; g.s = 0;
+    Ray<float> ray;
+    vec3<float> beta, L;
+    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f;
+
+    for (;;) {
+        // ---------------------------------------------------------------- regenerate
+        const unsigned long long want = __ballot(!alive && !finished);
+        const unsigned long long have = __ballot(alive);
+        if (want && (have == 0 || __popcll(want) >= regen_min)) {
+            if (!alive && !finished) {
+                // one LDS atomic per wave: the first fetching lane reserves a run of items for all fetching lanes; item =
+                // sample * 256 + slot, so simultaneous fetches are neighbouring pixels of one sample
+                const int leader = __ffsll(want) - 1;
+                unsigned int base = 0;
+                if (lane == leader) base = atomicAdd(item_counter, (unsigned int) __popcll(want));
+                base = __shfl(base, leader, 64);
+                const unsigned int item = base + (unsigned int) __popcll(want & ((1ull << lane) - 1ull));
+                if (item >= n_items) finished = true;
+                else {
+                    local = (int) (item & 255u);
+                    const int k = a.spp_begin + (int) (item >> 8);
+                    int j, i;
+                    pixel_of(local, j, i);
+                    if (j < a.width && i < a.y_end) {                                         // else: slot outside the image (edge tiles)
+                        g.seed(a.seed, (uint32_t) (i * a.width + j), (uint32_t) k);
+                        float x = (float(j) + uniform<float>(g)) / float(a.width - 1);         // raytracing.cpp:102-103
+                        float y = (float(i) + uniform<float>(g)) / float(a.height - 1);
+                        ray = camera_emit(sc.cam, g, x, y);
+                        beta = vec3<float>(1.f, 1.f, 1.f);
+                        L = vec3<float>();
+                        depth = a.max_depth;
+                        poisoned = false;
+                        path_rays = 0;
+                        alive = true;
+                        trav_begin(tv, ray);
+                    }
+                }
+            }
+        }
+        if (__ballot(!finished) == 0) break;
+        const int n_alive = __popcll(__ballot(alive));
+
+        // ---------------------------------------------------------------- traverse
+        for (;;) {
+            const int n_trav = __popcll(__ballot(tv.cur != RT_BVH_SENTINEL));
+            if (n_trav == 0 || n_trav * 256 < n_alive * trav_keep) break;
+            // inner nodes: while enough of the traversing lanes stand on one
+            for (;;) {
+                const int n_inner = __popcll(__ballot(tv.cur >= 0));
+                if (n_inner == 0 || n_inner * 256 < n_trav * node_keep) break;
+                if (tv.cur >= 0) {
+                    const BNode n = nodes[tv.cur];
+                    if (kCount && first_active_lane()) vs.w_node++;
+                    float tl, tr; bool hl, hr;
+                    slab_fma(n.lb, tv, t_min, tl, hl);
+                    slab_fma(n.rb, tv, t_min, tr, hr);
+                    if (kCount) vs.n_box += 2;
+                    if (hl && hr) {
+                        const bool left_first = tl <= tr;
+                        const int32_t far = left_first ? n.right : n.left;
+                        tv.cur = left_first ? n.left : n.right;
+                        tv.sp++;
+                        stack[tv.sp * 256] = (uint32_t) far;
+                    }
+                    else if (hl) tv.cur = n.left;
+                    else if (hr) tv.cur = n.right;
+                    else { tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--; }
+                }
+            }
+            // leaves
+            if (tv.cur < 0 && tv.cur != RT_BVH_SENTINEL) {
+                const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
+                for (int k = 0; k < count; k++) {
+                    float t;
+                    if (kCount && first_active_lane()) vs.w_leaf++;
+                    if (kCount) vs.n_leaf++;
+                    if (prim_t(fprims[first + k], ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
+                }
+                tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
+            }
+        }
+
+        // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
+        if (alive && tv.cur == RT_BVH_SENTINEL) {
+            n_rays++;
+            path_rays++;
+            if (kCount && first_active_lane()) vs.w_bounce++;
+            bool done = true;
+            if (tv.hit >= 0) {
+                Hit<float> h;
+                fill_record(fprims[tv.hit], sc.tris, ray, tv.closest, sc.need_uv != 0, h);
+                const Mat<float>& m = sc.mats[h.mat];
+                vec3<float> emission = mat_emit(sc, m, h);
+                Ray<float> wo; wo.time = 0.f;                                               // `ray wo;` raytracing.cpp:41
+                vec3<float> att;
+                bool spec = false;
+                L += beta * emission;
+                if (mat_shading(sc, g, m, ray, h, wo, att, spec)) {
+                    float pdf, mpdf;
+                    if (spec) {                                                             // raytracing.cpp:51-54
+                        mpdf = mat_pdf(g, m, h, wo);
+                        pdf = mpdf;
+                    }
+                    else {                                                                  // raytracing.cpp:55-61
+                        if (uniform<float>(g) < 0.5f) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                        mpdf = mat_pdf(g, m, h, wo);
+                        pdf = 0.5f * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                    }
+                    float inv = 1.0f / pdf;                                                 // raytracing.cpp:69, vec3.hpp:121-123
+                    vec3<float> w = mpdf * att;
+                    if (!rt_finite(inv) || !rt_finite(w.x) || !rt_finite(w.y) || !rt_finite(w.z)) poisoned = true;
+                    beta = beta * (inv * w);
+                    ray = wo;
+                    depth--;
+                    done = depth <= 0;
+                    if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
+                }
+            }
+            if (done) {
+                alive = false;
+                bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
+                if (bad) n_rejected++;
+                if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<float>(float(path_rays), bad ? 1.f : 0.f, 0.f); bad = false; }
+                if (!bad) {
+                    float* dst = tile_sum + local * 3;
+                    __hip_atomic_fetch_add(dst, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(dst + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            else trav_begin(tv, ray);
+        }
+    }
+
+    __syncthreads();
+    int j, i;
+    pixel_of((int) threadIdx.x, j, i);
+    if (j < a.width && i < a.y_end) {
+        float* out = accum + ((size_t) i * a.width + j) * 3;
+        const float sx = tile_sum[threadIdx.x * 3], sy = tile_sum[threadIdx.x * 3 + 1], sz = tile_sum[threadIdx.x * 3 + 2];
+        if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sx; out[1] += sy; out[2] += sz; }
+        else { out[0] = sx; out[1] = sy; out[2] = sz; }
+    }
+
+    // wave-level reduction of the counters, one atomic pair per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_rays += __shfl_down(n_rays, off, 64);
+        n_rejected += __shfl_down(n_rejected, off, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_rays);
+        if (n_rejected) atomicAdd(&counters[1], n_rejected);
+    }
+    if (kCount) {
+        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64);
+            wn += __shfl_down(wn, off, 64); wl += __shfl_down(wl, off, 64); wb += __shfl_down(wb, off, 64);
+        }
+        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); }
+    }
+}
+
+}  // namespace rt

@@ -8,6 +8,7 @@
 // Both precisions are resident so one scene serves the parity entry points and the fast renderer.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -74,6 +75,10 @@ struct rt_scene {
     int32_t n_lights = 0, n_prims = 0, n_ops = 0;
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
+    std::vector<void*> wf_owned;
+    uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
+    uint32_t trav_keep = 96, node_keep = 128, regen_min = 8;   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
@@ -345,6 +350,50 @@ __global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+
+// path pool of the wavefront renderer (rt_wavefront.h): allocated once per scene
+int wf_prepare(rt_scene* s)
+{
+    if (s->wf.pool.ctl) return RT_OK;
+    rt::WfBuffers b{};
+    const uint32_t cap = std::max(256u, s->wf_slots / 256u * 256u);
+    auto dev_alloc = [&](void** ptr, size_t bytes) -> bool {
+        if (hipMalloc(ptr, bytes) != hipSuccess) return false;
+        s->wf_owned.push_back(*ptr);
+        return true;
+    };
+    b.capacity = cap;
+    b.bvh_depth = s->d32.view.bvh_depth;
+    b.pool.lds_levels = (uint32_t) std::min(b.bvh_depth + 2, RT_WF_LDS_LEVELS_MAX);
+    int grid = 0;
+    if (rt::wf_extend_grid((int) b.pool.lds_levels, &grid) != hipSuccess) return fail(RT_EHIP, "occupancy query for wf_extend failed");
+    b.pool.extend_threads = (uint32_t) grid * 256u;
+    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wavefront pool: %u slots, tree depth %d, %u stack levels in LDS, wf_extend grid %d x 256\n", cap, b.bvh_depth, b.pool.lds_levels, grid);
+    const size_t spill_levels = (size_t) std::max(0, b.bvh_depth + 2 - (int) b.pool.lds_levels);
+    bool ok = dev_alloc((void**) &b.pool.ray_o, (size_t) cap * 16) && dev_alloc((void**) &b.pool.ray_d, (size_t) cap * 16) &&
+              dev_alloc((void**) &b.pool.hit, (size_t) cap * 8) && dev_alloc((void**) &b.pool.beta, (size_t) cap * 16) &&
+              dev_alloc((void**) &b.pool.rad, (size_t) cap * 16) && dev_alloc((void**) &b.pool.rng, (size_t) cap * 8) &&
+              dev_alloc((void**) &b.pool.item, (size_t) cap * 4) && dev_alloc((void**) &b.pool.wg_rays, (size_t) cap / 256 * 8) &&
+              dev_alloc((void**) &b.pool.wg_rejected, (size_t) cap / 256 * 8) &&
+              dev_alloc((void**) &b.pool.spill, std::max<size_t>(16, spill_levels * b.pool.extend_threads * 4)) &&
+              dev_alloc((void**) &b.pool.ctl, sizeof(rt::WfCtl));
+    if (ok && hipHostMalloc(&b.host_pinned, sizeof(rt::WfCtl) + 256) != hipSuccess) ok = false;
+    if (!ok) {
+        for (void* q : s->wf_owned) (void) hipFree(q);
+        s->wf_owned.clear();
+        return fail(RT_ENOMEM, "allocating the wavefront path pool failed");
+    }
+    s->wf = b;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 const char* rt_last_error(void) { return g_error.c_str(); }
 const char* rt_version(void) { return "rtcore-mi355x 0.1 (gfx950)"; }
 
@@ -365,6 +414,10 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (hipMalloc((void**) &s->counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
     if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
+    if (const char* env = std::getenv("RT_WF_SLOTS")) s->wf_slots = (uint32_t) std::min(64ll << 20, std::max(256ll, std::atoll(env)));
+    if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
     *scene_out = s;
     return RT_OK;
 }
@@ -373,6 +426,8 @@ int rt_scene_destroy(rt_scene* s)
 {
     if (!s) return RT_OK;
     release(s->d64); release(s->d32);
+    for (void* q : s->wf_owned) (void) hipFree(q);
+    if (s->wf.host_pinned) (void) hipHostFree(s->wf.host_pinned);
     if (s->counters) (void) hipFree(s->counters);
     if (s->ev0) (void) hipEventDestroy(s->ev0);
     if (s->ev1) (void) hipEventDestroy(s->ev1);
@@ -395,6 +450,23 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
+    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min;
+    if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
+        int rc = wf_prepare(s);
+        if (rc) return rc;
+        unsigned long long c[8] = { 0 };
+        HIP_TRY(hipEventRecord(s->ev0, st));
+        HIP_TRY(rt::wf_render(s->d32.view, a, s->wf, static_cast<float*>(accum_dev), c, st));
+        HIP_TRY(hipEventRecord(s->ev1, st));
+        HIP_TRY(hipEventSynchronize(s->ev1));
+        if (stats) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+            stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3];
+            stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
+        }
+        return RT_OK;
+    }
     HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->mode == RT_MODE_REFERENCE_FP64) {

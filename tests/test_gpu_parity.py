@@ -109,10 +109,12 @@ def test_render_fp64_matches_oracle_same_streams(R, golden_dir, name):
     osc.free()
 
 
-@pytest.mark.parametrize("mode_name", ["fast", "reftree"])
+@pytest.mark.parametrize("mode_name", ["fast", "reftree", "fast_lanesync", "fast_wavefront"])
 @pytest.mark.parametrize("name,early", [("c0_seed1", 0), ("obj", 0), ("c0_seed1", 1), ("mixed", 1), ("obj", 1)])
 def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name):
-    """fp32 modes (fast = own SAH tree, reftree = reference tree and visit order) vs the fp64 oracle on the same streams.  Tolerance: relative RMSE of the linear radiance <= 5 %
+    """fp32 modes (fast = own SAH tree, per-wave traverse/shade/regenerate state machine; fast_lanesync and fast_wavefront = the
+    same tree and arithmetic through the lane-synchronous loop and through the multi-kernel wavefront pipeline; reftree =
+    reference tree and visit order) vs the fp64 oracle on the same streams.  Tolerance: relative RMSE of the linear radiance <= 5 %
     at 16 spp (the Monte-Carlo noise of these small renders is ~30-60 %, so this is far inside the noise floor and only
     leaves room for paths whose branches flip under fp32 rounding), <= 2 % of 8-bit values off by more than 8 levels,
     ray counts within 1 %.  `mixed` is compared with early exit only: its phong-on-sphere paths continue, in the
@@ -125,8 +127,9 @@ def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name
     w, h, spp, depth = m["width"], m["height"], 16, min(m["depth"], 24)
     want, want_rgb, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=5, n_threads=8)
     sc = R.Scene(osc.export())
-    mode = R.MODE_FAST_FP32 if mode_name == "fast" else R.MODE_FP32_REFERENCE_TREE
-    got, rgb, stats = sc.render_to_host(w, h, 0, spp, depth, mode, seed=5, flags=R.FLAG_EARLY_EXIT if early else 0)
+    mode = R.MODE_FP32_REFERENCE_TREE if mode_name == "reftree" else R.MODE_FAST_FP32
+    variant = {"fast_lanesync": R.FLAG_LEGACY_LOOP, "fast_wavefront": R.FLAG_WAVEFRONT}.get(mode_name, 0)
+    got, rgb, stats = sc.render_to_host(w, h, 0, spp, depth, mode, seed=5, flags=(R.FLAG_EARLY_EXIT if early else 0) | variant)
     rmse = float(np.sqrt(np.mean((got - want) ** 2)) / max(np.sqrt(np.mean(want ** 2)), 1e-12))
     assert rmse < 0.05, rmse
     assert float((np.abs(rgb.astype(int) - want_rgb.astype(int)) > 8).mean()) < 0.02
