@@ -17,9 +17,9 @@ ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--level", type=int, default=8)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
-ap.add_argument("--trav", default="128")
-ap.add_argument("--node", default="1")
-ap.add_argument("--regen", default="1")
+ap.add_argument("--trav", default="0", help="0 = library default")
+ap.add_argument("--node", default="0")
+ap.add_argument("--regen", default="0")
 ap.add_argument("--count", action="store_true")
 ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* bits (16 legacy loop, 32 wavefront pipeline)")
 args = ap.parse_args()
@@ -36,7 +36,10 @@ else:
 acc = R.DeviceBuffer(w * h * 3 * 4)
 ints = lambda s: [int(x) for x in s.split(",")]
 for tk, nk, rm in itertools.product(ints(args.trav), ints(args.node), ints(args.regen)):
-    os.environ.update(RT_TRAV_KEEP=str(tk), RT_NODE_KEEP=str(nk), RT_REGEN_MIN=str(rm))
+    for name, v in (("RT_TRAV_KEEP", tk), ("RT_NODE_KEEP", nk), ("RT_REGEN_MIN", rm)):
+        os.environ.pop(name, None)
+        if v:
+            os.environ[name] = str(v)
     sc = hs.upload()
     sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags)
     t = min(sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags)["kernel_ms"] for _ in range(2))
