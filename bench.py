@@ -29,11 +29,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic cost model of the dominant kernel (DESIGN.md "Measurement"): per box test 3 rcp + 6 sub + 6 mul +
-# 6 select-compare + 3 cmp = 24 flop and one 32-B node record; per leaf test ~40 flop (sphere: 3 dots, disc, sqrt,
-# div, range tests) and one 64-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
+# algorithmic cost model of the dominant kernel (DESIGN.md "Measurement"): per box test 6 fma + 6 min/max + 4 = 22 flop
+# (fma = 2) and half a 64-B node record; per leaf test ~40 flop (triangle: 2 cross, 4 dot, 1 rcp; sphere: 3 dots, disc, sqrt,
+# div) and one 48-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
 FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
-BYTES_BOX, BYTES_LEAF = 32.0, 64.0   # fast tree: one 64-B node record per two box tests
+BYTES_BOX, BYTES_LEAF = 32.0, 48.0   # fast tree: one 64-B node record per two box tests
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_GBS = 150000.0      # aggregate ds_read_b64/b128 rate, every CU streaming (MI355X_MICROARCH.md, LDS)
@@ -177,8 +177,20 @@ def main():
         fetch_gbs = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
         peak = PEAK_FP32_TFLOPS if args.mode != "fp64" else PEAK_FP32_TFLOPS / 2
         d = host.desc.contents
-        scene_mb = (d.n_nodes * 64 + d.n_prims * 64) / 1e6
-        common = {"kernel": "rt::render_kernel", "traffic": None, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
+        scene_mb = (d.n_prims * 64 * 0.6 + d.n_prims * 48) / 1e6      # ~0.6 SAH nodes per primitive x 64 B + 48 B primitive records
+        # HBM-side bytes per launch: bytes per ray measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload at reduced spp (profiles/hbm_traffic.json, written by
+        # tools/hbm_traffic.py), scaled by this launch's ray count; null when no measurement of this workload is on file
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                rec = json.load(f).get(f"{args.workload}:{args.mode}:{w}x{h}:d{args.depth}")
+            if rec:
+                traffic = int(rec["bytes_per_ray"] * rays_per_launch)
+        except (OSError, ValueError):
+            pass
+        kernel_name = {"fp32": "rt::render_wave_kernel", "fp32ref": "rt::render_kernel<float>", "fp64": "rt::render_kernel<double>"}[args.mode]
+        common = {"kernel": kernel_name, "traffic": traffic, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
                   "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
                   "flop_per_ray": round(flop_per_ray, 1), "scene_bytes_per_ray": round(bytes_per_ray, 1), "scene_MB": round(scene_mb, 1),
                   "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1)}
@@ -187,8 +199,9 @@ def main():
             # (Infinity Cache / HBM).  achieved = algorithmic record bytes (tests per ray from the kernel's own counters x
             # record sizes) / kernel time, against the HBM peak.
             roofline = dict(common, bound="hbm", achieved=round(fetch_gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(fetch_gbs / PEAK_HBM_GBS, 4),
-                            note="algorithmic bytes = box_tests/2 x 64-B node + leaf_tests x 64-B primitive record per ray; records are served by "
-                                 "L2 + the 256 MiB Infinity Cache as well as HBM, so achieved can approach or pass the HBM-only peak")
+                            note="algorithmic bytes = box_tests/2 x 64-B node + leaf_tests x 48-B primitive record per ray; records are served by "
+                                 "L1/L2 + the 256 MiB Infinity Cache as well as HBM (traffic = memory-side bytes), so achieved can approach or "
+                                 "pass the HBM-only peak; the kernel's binding limits are VALU issue and the vector-memory address path, see valu_TFLOPs")
         else:
             roofline = dict(common, bound="valu", achieved=round(achieved_tflops, 3), peak=peak, unit="TFLOP/s", frac=round(achieved_tflops / peak, 4),
                             note="scene fits L1/L2: no HBM stream to be bound by (HBM traffic = the frame buffer once per launch); "

@@ -117,6 +117,7 @@ typedef struct rt_render_stats {
     uint64_t wave_node_steps;    /* RT_FLAG_COUNT_TESTS, fast mode: wave-level iterations of the node loop (x64 lanes = issue slots) */
     uint64_t wave_leaf_steps;    /* ... of the leaf-test loop */
     uint64_t wave_bounces;       /* ... of the bounce loop */
+    uint64_t phase_ticks[4];     /* RT_FLAG_COUNT_TESTS, fast mode: wave time (100 MHz ticks, summed over waves) in the regenerate, node, leaf and shade phases */
 } rt_render_stats;
 
 /* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit

@@ -57,9 +57,13 @@ template <typename R> struct alignas(8) Op {
     int32_t prim;
 };
 // hot primitive record (intersection only).  g[]: sphere c,r | msphere c0,c1,start,end,r | plane a0,a1,b0,b1,k | triangle p0,e1,e2
+// 48 B in fp32: three 16-byte loads fetch any primitive.
 template <typename R> struct alignas(16) Prim {
-    R g[12];
-    int32_t kind, flags, mat, id;   // id: primitive id (index into tris[]); records may be stored in any order
+    R g[9];
+    int32_t kf;                     // kind | flags << 8
+    int32_t mat, id;                // id: primitive id (index into tris[]); records may be stored in any order
+    __host__ __device__ int kind() const { return kf & 0xff; }
+    __host__ __device__ int flags() const { return kf >> 8; }
 };
 // Fast-mode BVH node (64 B, one cache line): both children's boxes live in the parent, so one fetch decides both.
 // Child code c >= 0: inner node c; c < 0: leaf, ~c = first_record * 8 + (count - 1) into Scene::fprims (<= 8 records).
@@ -264,8 +268,8 @@ template <typename R> __device__ inline void plane_split(int kind, const vec3<R>
 template <typename R> __device__ inline bool plane_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t, R& a, R& b)
 {                                                                                                         // primitive.hpp:176-187 / 227-238 / 296-307
     R oa, ob, ok, da, db, dk;
-    plane_split(p.kind, r.o, oa, ob, ok);
-    plane_split(p.kind, r.d, da, db, dk);
+    plane_split(p.kind(), r.o, oa, ob, ok);
+    plane_split(p.kind(), r.d, da, db, dk);
     R tt = (p.g[4] - ok) / dk;
     if (tt < t_min || tt > t_max) return false;
     a = oa + tt * da;
@@ -314,12 +318,12 @@ template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const Ray<
     R a, b;
     if constexpr (sizeof(R) == sizeof(float)) {
         if (p.id == r.from) {
-            if (p.kind == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
-            if (p.kind == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
+            if (p.kind() == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
+            if (p.kind() == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
             return false;
         }
     }
-    switch (p.kind) {
+    switch (p.kind()) {
     case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
@@ -351,11 +355,11 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
     h.mat = p.mat;
     h.id = p.id;
     h.u = h.v = R(0);
-    switch (p.kind) {
+    switch (p.kind()) {
     case RT_PRIM_SPHERE:
     case RT_PRIM_MSPHERE: {
-        vec3<R> c = p.kind == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);
-        R radius = p.kind == RT_PRIM_SPHERE ? p.g[3] : p.g[8];
+        vec3<R> c = p.kind() == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);
+        R radius = p.kind() == RT_PRIM_SPHERE ? p.g[3] : p.g[8];
         h.pos = r.o + t * r.d;
         vec3<R> n = (h.pos - c) / radius;
         set_face_normal(h, r, n);
@@ -382,19 +386,19 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
     }
     default: {
         R oa, ob, ok, da, db, dk;
-        plane_split(p.kind, r.o, oa, ob, ok);
-        plane_split(p.kind, r.d, da, db, dk);
+        plane_split(p.kind(), r.o, oa, ob, ok);
+        plane_split(p.kind(), r.d, da, db, dk);
         R a = oa + t * da;
         R b = ob + t * db;
         h.u = (a - p.g[0]) / (p.g[1] - p.g[0]);
         h.v = (b - p.g[2]) / (p.g[3] - p.g[2]);
-        vec3<R> n(p.kind == RT_PRIM_PLANEYZ ? R(1) : R(0), p.kind == RT_PRIM_PLANEXZ ? R(1) : R(0), p.kind == RT_PRIM_PLANEXY ? R(1) : R(0));
+        vec3<R> n(p.kind() == RT_PRIM_PLANEYZ ? R(1) : R(0), p.kind() == RT_PRIM_PLANEXZ ? R(1) : R(0), p.kind() == RT_PRIM_PLANEXY ? R(1) : R(0));
         set_face_normal(h, r, n);
         h.pos = r.o + t * r.d;
         break;
     }
     }
-    if (p.flags & RT_PRIM_FLAG_FLIP) h.front = !h.front;
+    if (p.flags() & RT_PRIM_FLAG_FLIP) h.front = !h.front;
 }
 
 struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; uint32_t w_node, w_leaf, w_bounce; };   // w_*: wave-level loop iterations (counted by the first active lane)
@@ -649,13 +653,13 @@ template <typename R> __device__ inline R light_pdf(const Scene<R>& sc, int li, 
     R t, a, b;
     vec3<R> normal;
     R area;
-    if (p.kind == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:258-269
+    if (p.kind() == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:258-269
         if (!plane_t(p, r, consts<R>::tmin, rt_inf<R>(), t, a, b)) return R(0);
         vec3<R> n(R(0), R(1), R(0));
         normal = dot(r.d, n) < R(0) ? n : -n;
         area = (p.g[1] - p.g[0]) * (p.g[3] - p.g[2]);
     }
-    else if (p.kind == RT_PRIM_TRIANGLE) {                                                  // polygon.hpp:140-151
+    else if (p.kind() == RT_PRIM_TRIANGLE) {                                                  // polygon.hpp:140-151
         R u, v;
         if (!tri_t(p, r, consts<R>::tmin, rt_inf<R>(), t, u, v)) return R(0);
         const TriShade<R>& s = sc.light_tris[li];
@@ -678,12 +682,12 @@ template <typename R> __device__ inline vec3<R> light_rand(const Scene<R>& sc, R
     int idx = (int) uniform<R>(g, R(0), R(sc.n_lights));                                    // group.hpp:117, util.hpp:42-45
     if (idx >= sc.n_lights) idx = sc.n_lights - 1;                                          // fp32 only: guards u*n rounding up to n
     const Prim<R>& p = sc.lights[idx];
-    if (p.kind == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:270-274
+    if (p.kind() == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:270-274
         R z = uniform<R>(g, p.g[2], p.g[3]);
         R x = uniform<R>(g, p.g[0], p.g[1]);
         return vec3<R>(x, p.g[4], z) - origin;
     }
-    if (p.kind == RT_PRIM_TRIANGLE) {                                                       // polygon.hpp:153-167
+    if (p.kind() == RT_PRIM_TRIANGLE) {                                                       // polygon.hpp:153-167
         vec3<R> p0(p.g[0], p.g[1], p.g[2]), e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
         R u = uniform<R>(g), v = uniform<R>(g);
         vec3<R> q = (u + v > R(1)) ? (p0 + (R(1) - u) * e1) + (R(1) - v) * e2 : (p0 + u * e1) + v * e2;

@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
     vec3<float> beta, L;
     Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f;
 
+    unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // diagnostic: wave time per phase (regenerate, nodes, leaves, shade)
+    auto lap = [&](int phase) { if (kCount) { const unsigned long long t1 = wall_clock64(); cyc[phase] += t1 - t0; t0 = t1; } };
+
     for (;;) {
         // ---------------------------------------------------------------- regenerate
         const unsigned long long want = __ballot(!alive && !finished);
@@ -125,6 +128,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
         }
         if (__ballot(!finished) == 0) break;
         const int n_alive = __popcll(__ballot(alive));
+        lap(0);
 
         // ---------------------------------------------------------------- traverse
         for (;;) {
@@ -153,6 +157,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                     else { tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--; }
                 }
             }
+            lap(1);
             // leaves
             if (tv.cur < 0 && tv.cur != RT_BVH_SENTINEL) {
                 const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
@@ -164,6 +169,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                 }
                 tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
             }
+            lap(2);
         }
 
         // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
@@ -216,6 +222,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
             }
             else trav_begin(tv, ray);
         }
+        lap(3);
     }
 
     __syncthreads();
@@ -245,7 +252,10 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
             nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64);
             wn += __shfl_down(wn, off, 64); wl += __shfl_down(wl, off, 64); wb += __shfl_down(wb, off, 64);
         }
-        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); }
+        if (lane == 0) {
+            atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb);
+            for (int k = 0; k < 4; k++) atomicAdd(&counters[8 + k], cyc[k]);
+        }
     }
 }
 

@@ -2,7 +2,7 @@
 //
 // HBM layout built here from rt_scene_desc (all arrays are flat, index-linked; no pointers inside records):
 //   ops   : the reference BVH in pre-order, one record per bvh node / leaf reference (Op<R>, 32 B fp32 / 56 B fp64)
-//   prims : hot intersection records by primitive id (Prim<R>, 64 B fp32 / 112 B fp64)
+//   prims : hot intersection records by primitive id (Prim<R>, 48 B fp32 / 96 B fp64)
 //   tris  : cold per-triangle shading records (normals + uvs), only when the scene has triangles
 //   mats, texs, pixels, lights, light_tris
 // Both precisions are resident so one scene serves the parity entry points and the fast renderer.
@@ -171,7 +171,7 @@ int linearize(const rt_scene_desc* d, Flat& f)
 template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g, int id)
 {
     std::memset(&p, 0, sizeof p);
-    p.kind = kind; p.flags = flags; p.mat = mat; p.id = id;
+    p.kf = kind | (flags << 8); p.mat = mat; p.id = id;
     int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : 5;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
     if (tri) {
@@ -411,7 +411,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (e != hipSuccess) { delete s; return fail(RT_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e) + " (no HIP device: the HIP path is the only path)"); }
     if ((rc = build_device<double>(desc, f, s->d64)) || (rc = build_device<float>(desc, f, s->d32))) { rt_scene_destroy(s); return rc; }
     s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
-    if (hipMalloc((void**) &s->counters, 8 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
+    if (hipMalloc((void**) &s->counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
     if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
     if (const char* env = std::getenv("RT_WF_SLOTS")) s->wf_slots = (uint32_t) std::min(64ll << 20, std::max(256ll, std::atoll(env)));
@@ -464,10 +464,11 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
             HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
             stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3];
             stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
+            for (int k = 0; k < 4; k++) stats->phase_ticks[k] = 0;
         }
         return RT_OK;
     }
-    HIP_TRY(hipMemsetAsync(s->counters, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->mode == RT_MODE_REFERENCE_FP64) {
         if ((size_t) s->d64.ops_bytes + s->d64.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d64.ops_bytes; a.lds_prims_bytes = s->d64.prims_bytes; }
@@ -483,8 +484,9 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         HIP_TRY(hipEventSynchronize(s->ev1));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-        unsigned long long c[8];
+        unsigned long long c[16];
         HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; k++) stats->phase_ticks[k] = c[8 + k];
         stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
     }
     return RT_OK;

@@ -45,7 +45,7 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rejected_samples", C.c_uint64), ("kernel_ms", C.c_double), ("box_tests", C.c_uint64), ("leaf_tests", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64), ("phase_ticks", C.c_uint64 * 4)]
 
 
 _lib = None
@@ -177,7 +177,7 @@ class Scene:
         _check(load_library().rt_render(self.h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st) if want_stats else None))
         return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms), box_tests=int(st.box_tests),
                     leaf_tests=int(st.leaf_tests), wave_node_steps=int(st.wave_node_steps), wave_leaf_steps=int(st.wave_leaf_steps),
-                    wave_bounces=int(st.wave_bounces)) if want_stats else None
+                    wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks]) if want_stats else None
 
     def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0):
         """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats)."""
