@@ -40,8 +40,13 @@ extern "C" {
 #define RT_PRIM_PLANEXZ  4  /* planexz  primitive.hpp:209-275  data: x0,x1,z0,z1,k                      */
 #define RT_PRIM_PLANEYZ  5  /* planeyz  primitive.hpp:278-326  data: y0,y1,z0,z1,k                      */
 #define RT_PRIM_TRIANGLE 6  /* triangle polygon.hpp:23-183     data: p0[3], p0p1[3], p0p2[3], n0[3], n1[3], n2[3], uv0[2], uv1[2], uv2[2] */
+#define RT_PRIM_BOX      7  /* box      primitive.hpp:399-458, optionally inside rotatey and then translate (transform.hpp:9-121), as
+                               cornell_box() builds it (demo.hpp:80-88): one leaf of the bvh.
+                               data: minimum[3], maximum[3], sin_theta, cos_theta, target[3]                  */
 #define RT_PRIM_STRIDE  24  /* doubles per primitive record */
 #define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` */
+#define RT_PRIM_FLAG_ROTATEY 2   /* RT_PRIM_BOX: wrapped in rotatey (sin_theta, cos_theta as its constructor computes them) */
+#define RT_PRIM_FLAG_TRANSLATE 4 /* RT_PRIM_BOX: wrapped (outermost) in translate(target) */
 
 /* material kinds (material.hpp) and the layout of their RT_MAT_STRIDE doubles */
 #define RT_MAT_LAMBERTIAN 1 /* tex = base_color                                  */

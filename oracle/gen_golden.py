@@ -130,6 +130,8 @@ def main():
         "c0_seed7": (["c0", 7, 96, 64, 4, 50], dict(seed=7, width=96, height=64, spp=4, depth=50)),
         "mixed": (["mixed", 3, 64, 48, 16, 20], dict(seed=3, width=64, height=48, spp=16, depth=20)),
         "obj": (["obj", obj, 5, 64, 48, 8, 12], dict(seed=5, width=64, height=48, spp=8, depth=12)),
+        # the reference's own main() scene (raytracing.cpp:77-90: Cornell box, depth 10) at a small size
+        "cornell": (["cornell", 1, 56, 56, 16, 10], dict(seed=1, width=56, height=56, spp=16, depth=10)),
     }
     for name, (args, meta) in jobs.items():
         with tempfile.TemporaryDirectory() as tmp:

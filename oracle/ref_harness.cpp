@@ -70,10 +70,23 @@ static double sm_unit() { return (sm_next() >> 11) * (1.0 / 9007199254740992.0);
 static double sm_range(double a, double b) { return a + (b - a) * sm_unit(); }
 
 // ---------------------------------------------------------------- tree dump
-enum { K_NODE = 0, K_SPHERE = 1, K_MSPHERE = 2, K_PLANEXY = 3, K_PLANEXZ = 4, K_PLANEYZ = 5, K_TRIANGLE = 6 };
+enum { K_NODE = 0, K_SPHERE = 1, K_MSPHERE = 2, K_PLANEXY = 3, K_PLANEXZ = 4, K_PLANEYZ = 5, K_TRIANGLE = 6, K_BOX = 7 };
 enum { ROW = 56 };   // doubles per pre-order entry
 
-struct pentry { const object* o; const object* base; int flipped; int left; int right; };
+struct pentry {
+    const object* o; const object* base; int flipped; int left; int right;
+    int xf = 0; double sin_t = 0, cos_t = 1; vec3d target;     // translate(rotatey(box)) wrappers: bit 1 rotatey, bit 2 translate
+};
+// strips flip / translate / rotatey wrappers (transform.hpp), outermost first
+static void unwrap(pentry& e)
+{
+    for (;;) {
+        if (const flip* f = dynamic_cast<const flip*>(e.base)) { e.base = f->obj; e.flipped ^= 1; }
+        else if (const translate* t = dynamic_cast<const translate*>(e.base)) { e.base = t->obj; e.target = t->target; e.xf |= 4; }
+        else if (const rotatey* r = dynamic_cast<const rotatey*>(e.base)) { e.base = r->obj; e.sin_t = r->sin_theta; e.cos_t = r->cos_theta; e.xf |= 2; }
+        else break;
+    }
+}
 
 struct tree_dump {
     std::vector<pentry> pre;
@@ -83,7 +96,7 @@ struct tree_dump {
     {
         int idx = (int) pre.size();
         pentry e; e.o = o; e.base = o; e.flipped = 0; e.left = e.right = -1;
-        while (const flip* f = dynamic_cast<const flip*>(e.base)) { e.base = f->obj; e.flipped ^= 1; }
+        unwrap(e);
         pre.push_back(e);
         if (!first.count(o)) first[o] = idx;
         if (const bvh* b = dynamic_cast<const bvh*>(o)) {
@@ -161,6 +174,14 @@ struct tree_dump {
                 }
                 for (int v = 0; v < 3; v++) { g[18 + 2 * v] = t->vertices[v].uv_coord.content[0]; g[19 + 2 * v] = t->vertices[v].uv_coord.content[1]; }
                 mat = t->mat;
+            } else if (const box* bx = dynamic_cast<const box*>(e.base)) {
+                // box (primitive.hpp:399-458) under translate(rotatey(.)) (transform.hpp:9-121): one leaf of the bvh
+                r[0] = K_BOX; r[3] = e.xf;
+                for (int k = 0; k < 3; k++) { g[k] = bx->minimum[k]; g[3 + k] = bx->maximum[k]; g[8 + k] = e.target[k]; }
+                g[6] = e.sin_t; g[7] = e.cos_t;
+                aabb bb; e.o->bounding_box(0, 0, bb);          // the wrapped object's box, as the bvh builder sees it
+                for (int k = 0; k < 3; k++) { g[11 + k] = bb.min()[k]; g[14 + k] = bb.max()[k]; }
+                mat = dynamic_cast<const planexy*>(bx->xy0)->mat;
             } else {
                 r[0] = -1;
             }
@@ -253,6 +274,22 @@ static built_scene* build_mixed(int w, int h)
     return b;
 }
 
+// the scene of the reference's own main(): raytracing.cpp:77-88 (cornell_box(), demo.hpp:63-91)
+static built_scene* build_cornell(int w, int h)
+{
+    built_scene* b = new built_scene();
+    camera cam = camera(vec3d(278, 278, -800), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, 1, 0, 1, 0, 1);
+    object* light = new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30))));
+    b->scn = new scene(w, h);
+    b->scn->add_object(cornell_box());
+    b->scn->add_light(light);
+    b->scn->set_camera(cam);
+    b->scn->build_bvh();
+    b->root = b->scn->objects.content()[0];
+    b->td.walk(b->root);
+    return b;
+}
+
 // OBJ scene through the reference loader (loader.hpp:20-38)
 static built_scene* build_obj(const char* path, int w, int h)
 {
@@ -283,7 +320,7 @@ static void dump_lights(const char* name, const scene& scn)
     for (int i = 0; i < scn.lights->size(); i++) {
         const object* o = scn.lights->content()[i];
         pentry e; e.o = o; e.base = o; e.flipped = 0; e.left = e.right = -1;
-        while (const flip* f = dynamic_cast<const flip*>(e.base)) { e.base = f->obj; e.flipped ^= 1; }
+        unwrap(e);
         td.first[o] = (int) td.pre.size();
         td.pre.push_back(e);
     }
@@ -573,6 +610,17 @@ int main(int argc, char** argv)
         double lo[3] = { -2.5, -0.1, -2.5 }, hi[3] = { 2.5, 3, 2.5 };
         do_firsthit("obj", b, 32, 1024, lo, hi);
         do_image("obj", b, w, h, spp, depth);
+    }
+    else if (mode == "cornell") {       // cornell <seed> <w> <h> <spp> <depth>
+        unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+        srand(seed);
+        built_scene* b = build_cornell(w, h);
+        dump_f64("cornell_tree", b->td.rows());
+        dump_lights("cornell_lights", *b->scn);
+        dump_camera("cornell_camera", b->scn->render_camera);
+        double lo[3] = { 1, 1, 1 }, hi[3] = { 554, 554, 554 };
+        do_firsthit("cornell", b, 48, 1600, lo, hi);
+        do_image("cornell", b, w, h, spp, depth);
     }
     else if (mode == "time_c0") {       // time_c0 <seed> <w> <h> <spp> <depth> : throughput of the real reference, 1 thread
         unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);

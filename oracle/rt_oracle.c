@@ -453,6 +453,61 @@ static int tri_hit(const orc_obj* o, const ray* r, isect* x)            /* polyg
     return 1;
 }
 
+/* box (primitive.hpp:399-458: six rects tested in a group, group.hpp:68-83) under rotatey and translate
+ * (transform.hpp:9-121).  g[0..5] min,max  g[6] sin  g[7] cos  g[8..10] target  g[11] wrappers: 2 rotatey | 4 translate */
+static int box_hit(const orc_obj* o, const ray* r, isect* x)
+{
+    const double* g = o->g;
+    const int xf = (int) g[11];
+    const v3 target = V(g[8], g[9], g[10]);
+    const double sn = g[6], cs = g[7];
+    ray tr = *r;                                                         /* translate::intersect, transform.hpp:18-28 */
+    if (xf & 4) tr = mkray(vsub(r->o, target), r->d, r->time, r->t_min, r->t_max);
+    ray rr = tr;                                                         /* rotatey::intersect, transform.hpp:81-110 */
+    if (xf & 2) {
+        v3 origin = tr.o, direction = tr.d;
+        origin.x = cs * tr.o.x - sn * tr.o.z;
+        origin.z = sn * tr.o.x + cs * tr.o.z;
+        direction.x = cs * tr.d.x - sn * tr.d.z;
+        direction.z = sn * tr.d.x + cs * tr.d.z;
+        rr = mkray(origin, direction, tr.time, tr.t_min, tr.t_max);
+    }
+    orc_obj side[6];                                                     /* box ctor, primitive.hpp:409-431 */
+    memset(side, 0, sizeof side);
+    const double lo[3] = { g[0], g[1], g[2] }, hi[3] = { g[3], g[4], g[5] };
+    for (int i = 0; i < 6; i++) side[i].mat = o->mat;
+    side[0].kind = side[1].kind = ORC_PLANEXY; side[2].kind = side[3].kind = ORC_PLANEXZ; side[4].kind = side[5].kind = ORC_PLANEYZ;
+    for (int i = 0; i < 2; i++) {
+        double* a = side[i].g; a[0] = lo[0]; a[1] = hi[0]; a[2] = lo[1]; a[3] = hi[1]; a[4] = i ? lo[2] : hi[2];
+        double* b = side[2 + i].g; b[0] = lo[0]; b[1] = hi[0]; b[2] = lo[2]; b[3] = hi[2]; b[4] = i ? lo[1] : hi[1];
+        double* c = side[4 + i].g; c[0] = lo[1]; c[1] = hi[1]; c[2] = lo[2]; c[3] = hi[2]; c[4] = i ? lo[0] : hi[0];
+    }
+    isect tmp; memset(&tmp, 0, sizeof tmp);                              /* box::intersect -> group::intersect */
+    int has = 0;
+    double closest = rr.t_max;
+    for (int i = 0; i < 6; i++) {
+        ray q = mkray(rr.o, rr.d, rr.time, rr.t_min, closest);
+        if (plane_hit(&side[i], &q, &tmp)) { has = 1; closest = tmp.t; *x = tmp; }
+    }
+    if (!has) return 0;
+    if (xf & 2) {                                                        /* transform.hpp:99-110 */
+        v3 position = x->pos, normal = x->normal;
+        position.x = cs * x->pos.x + sn * x->pos.z;
+        position.z = -sn * x->pos.x + cs * x->pos.z;
+        normal.x = cs * x->normal.x + sn * x->normal.z;
+        normal.z = -sn * x->normal.x + cs * x->normal.z;
+        x->pos = position;
+        set_face_normal(x, &rr, normal);
+    }
+    if (xf & 4) {                                                        /* transform.hpp:25-27 */
+        x->pos = vadd(x->pos, target);
+        set_face_normal(x, &tr, x->normal);
+    }
+    x->mat = o->mat;
+    x->leaf = o;
+    return 1;
+}
+
 static int obj_hit(const orc_obj* o, const ray* r, isect* x);
 
 static int bvh_hit(const orc_obj* o, const ray* r, isect* x)            /* bvh.hpp:58-68 */
@@ -472,6 +527,7 @@ static int obj_hit(const orc_obj* o, const ray* r, isect* x)
     case ORC_MSPHERE: return sphere_hit(o, msphere_center(o, r->time), o->g[8], r, x);
     case ORC_PLANEXY: case ORC_PLANEXZ: case ORC_PLANEYZ: return plane_hit(o, r, x);
     case ORC_TRIANGLE: return tri_hit(o, r, x);
+    case ORC_BOX: return box_hit(o, r, x);
     case O_FLIP:                                                        /* transform.hpp:129-136 */
         if (!obj_hit(o->l, r, x)) return 0;
         x->front = !x->front;
@@ -521,6 +577,25 @@ static int obj_bbox(const orc_obj* o, double start, double end, aabb* out)
             mn[k] = lo - ORC_EPS; mx[k] = hi + ORC_EPS;
         }
         out->mn = V(mn[0], mn[1], mn[2]); out->mx = V(mx[0], mx[1], mx[2]); return 1;
+    }
+    case ORC_BOX: {                                                     /* primitive.hpp:441-445, transform.hpp:51-79, 30-37 */
+        const double* g = o->g;
+        const int xf = (int) g[11];
+        aabb b; b.mn = V(g[0], g[1], g[2]); b.mx = V(g[3], g[4], g[5]);
+        if (xf & 2) {
+            double mn[3] = { ORC_INF, ORC_INF, ORC_INF }, mx[3] = { -ORC_INF, -ORC_INF, -ORC_INF };
+            for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+                double px = i * b.mx.x + (1 - i) * b.mn.x;
+                double py = j * b.mx.y + (1 - j) * b.mn.y;
+                double pz = k * b.mx.z + (1 - k) * b.mn.z;
+                double t[3] = { g[7] * px + g[6] * pz, py, -g[6] * px + g[7] * pz };
+                for (int l = 0; l < 3; l++) { mn[l] = fmin(mn[l], t[l]); mx[l] = fmax(mx[l], t[l]); }
+            }
+            b.mn = V(mn[0], mn[1], mn[2]); b.mx = V(mx[0], mx[1], mx[2]);
+        }
+        if (xf & 4) { v3 target = V(g[8], g[9], g[10]); b.mn = vadd(b.mn, target); b.mx = vadd(b.mx, target); }
+        *out = b;
+        return 1;
     }
     case O_FLIP: return obj_bbox(o->l, start, end, out);                /* transform.hpp:138-141 */
     case O_BVH: *out = o->box; return 1;                                /* bvh.hpp:70-74 */
@@ -761,6 +836,17 @@ int orc_add_msphere(orc_scene* s, const double c0[3], const double c1[3], double
 int orc_add_plane(orc_scene* s, int kind, double a0, double a1, double b0, double b1, double k, int mat, int flip, int to_lights)
 { orc_obj* o = new_obj(kind); o->mat = mat; o->g[0] = a0; o->g[1] = a1; o->g[2] = b0; o->g[3] = b1; o->g[4] = k; return finish_add(s, o, flip, to_lights); }
 
+/* box(minimum, maximum, mat), optionally wrapped rotatey(., angle) then translate(., target); sin/cos as the rotatey ctor
+ * computes them (transform.hpp:50-52: sin/cos of angle * pi / 180 with util.hpp's truncated pi) */
+int orc_add_box(orc_scene* s, const double mn[3], const double mx[3], int wrappers, double sin_theta, double cos_theta, const double target[3],
+                int mat, int flip, int to_lights)
+{
+    orc_obj* o = new_obj(ORC_BOX); o->mat = mat;
+    for (int k = 0; k < 3; k++) { o->g[k] = mn[k]; o->g[3 + k] = mx[k]; o->g[8 + k] = (wrappers & 4) ? target[k] : 0.0; }
+    o->g[6] = (wrappers & 2) ? sin_theta : 0.0; o->g[7] = (wrappers & 2) ? cos_theta : 1.0; o->g[11] = wrappers & 6;
+    return finish_add(s, o, flip, to_lights);
+}
+
 static orc_obj* mk_triangle(const double p[9], const double n[9], const double uv[6], int mat)   /* polygon.hpp:26-38 */
 {
     orc_obj* o = new_obj(ORC_TRIANGLE); o->mat = mat;
@@ -795,6 +881,7 @@ void orc_add_prims_bulk(orc_scene* s, int n, const int32_t* kind, const int32_t*
         switch (kind[i]) {
         case ORC_SPHERE: orc_add_sphere(s, g, g[3], mat[i], fl, to_lights); break;
         case ORC_MSPHERE: orc_add_msphere(s, g, g + 3, g[6], g[7], g[8], mat[i], fl, to_lights); break;
+        case ORC_BOX: orc_add_box(s, g, g + 3, flags[i] & 6, g[6], g[7], g + 8, mat[i], fl, to_lights); break;
         case ORC_TRIANGLE: {
             double p[9];
             for (int k = 0; k < 3; k++) { p[k] = g[k]; p[3 + k] = g[k] + g[3 + k]; p[6 + k] = g[k] + g[6 + k]; }
@@ -937,6 +1024,33 @@ orc_scene* orc_build_mixed(int width, int height, unsigned seed)
     return s;
 }
 
+/* the reference's own main() scene: raytracing.cpp:77-88 over cornell_box() (demo.hpp:63-91) */
+orc_scene* orc_build_cornell(int width, int height, unsigned seed)
+{
+    orc_scene* s = orc_scene_new(width, height, seed);
+    int red = orc_mat_lambertian(s, orc_tex_constant(s, 0.65, 0.05, 0.05));
+    int green = orc_mat_lambertian(s, orc_tex_constant(s, 0.12, 0.45, 0.15));
+    int white = orc_mat_lambertian(s, orc_tex_constant(s, 0.75, 0.75, 0.75));
+    int light = orc_mat_emissive(s, orc_tex_constant(s, 30, 30, 30));
+    int mirror = orc_mat_metal(s, orc_tex_constant(s, 1, 1, 1), 0);
+    orc_add_plane(s, ORC_PLANEYZ, 0, 555, 0, 555, 555, green, 0, 0);
+    orc_add_plane(s, ORC_PLANEYZ, 0, 555, 0, 555, 0, red, 0, 0);
+    orc_add_plane(s, ORC_PLANEXZ, 0, 555, 0, 555, 0, white, 0, 0);
+    orc_add_plane(s, ORC_PLANEXZ, 0, 555, 0, 555, 555, white, 0, 0);
+    orc_add_plane(s, ORC_PLANEXY, 0, 555, 0, 555, 555, white, 0, 0);
+    orc_add_plane(s, ORC_PLANEXZ, 213, 343, 227, 332, 554, light, 1, 0);
+    double zero[3] = { 0, 0, 0 }, b1[3] = { 165, 330, 165 }, b2[3] = { 165, 165, 165 }, t1[3] = { 265, 0, 295 }, t2[3] = { 130, 0, 65 };
+    double a1 = 15 * ORC_PI / 180, a2 = -18 * ORC_PI / 180;               /* util.hpp:24-27 */
+    orc_add_box(s, zero, b1, 6, sin(a1), cos(a1), t1, mirror, 0, 0);
+    orc_add_box(s, zero, b2, 6, sin(a2), cos(a2), t2, white, 0, 0);
+    int light2 = orc_mat_emissive(s, orc_tex_constant(s, 30, 30, 30));
+    orc_add_plane(s, ORC_PLANEXZ, 213, 343, 227, 332, 554, light2, 1, 1);
+    double pos[3] = { 278, 278, -800 }, at[3] = { 278, 278, 0 }, up[3] = { 0, 1, 0 };
+    orc_set_camera(s, pos, at, up, 40, 0, 1, 0, 1);
+    orc_build_bvh(s);
+    return s;
+}
+
 /* ------------------------------------------------------------------ pre-order view */
 static int pre_walk(orc_scene* s, const orc_obj* o, int* cap)
 {
@@ -1006,8 +1120,13 @@ static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int lef
         return;
     }
     r[0] = base->kind;
-    int ng = base->kind == ORC_SPHERE ? 4 : base->kind == ORC_MSPHERE ? 9 : base->kind == ORC_TRIANGLE ? 24 : 5;
+    int ng = base->kind == ORC_SPHERE ? 4 : base->kind == ORC_MSPHERE ? 9 : base->kind == ORC_TRIANGLE ? 24 : base->kind == ORC_BOX ? 11 : 5;
     for (int k = 0; k < ng; k++) g[k] = base->g[k];
+    if (base->kind == ORC_BOX) {                                        /* ref_harness.cpp tree_dump::rows, K_BOX */
+        aabb bb; obj_bbox(o, 0, 0, &bb);
+        r[3] = base->g[11];
+        g[11] = bb.mn.x; g[12] = bb.mn.y; g[13] = bb.mn.z; g[14] = bb.mx.x; g[15] = bb.mx.y; g[16] = bb.mx.z;
+    }
     if (base->mat >= 0) put_mat_row(s, base->mat, m);
 }
 
@@ -1074,6 +1193,7 @@ static void export_prim(const orc_obj* o, int32_t* kind, int32_t* flags, int32_t
     *kind = base->kind; *flags = flipped; *mat = base->mat;
     memset(data, 0, sizeof(double) * ORC_PRIM_STRIDE);
     memcpy(data, base->g, sizeof(double) * ORC_PRIM_STRIDE);
+    if (base->kind == ORC_BOX) { *flags |= (int) base->g[11]; data[11] = 0; }   /* wrappers travel as RT_PRIM_FLAG_ROTATEY / _TRANSLATE */
 }
 void orc_export(const orc_scene* s, double* node_bbox, int32_t* node_child, int32_t* roots,
                 int32_t* prim_kind, int32_t* prim_flags, int32_t* prim_mat, double* prim_data,

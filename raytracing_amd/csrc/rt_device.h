@@ -79,7 +79,8 @@ struct alignas(16) BNode {
 #define RT_WAVES_FP32 4   // waves per SIMD the fp32 render kernels are compiled for (<= 128 VGPRs)
 #endif
 
-// cold triangle record (shading only): vertex normals and uvs
+// per-primitive side record, by primitive id.  Triangles: vertex normals and uvs (cold: read once per hit).  Boxes: n[0..2] is the
+// translate target (read by the box test).
 template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
 template <typename R> struct Mat { int32_t kind, tex; R d[16]; };
 template <typename R> struct Tex { int32_t kind, a, b, ch, color_based; uint32_t offset; R rgb[3]; R pad; };
@@ -88,7 +89,7 @@ template <typename R> struct Camera { vec3<R> pos, left_bottom, horizontal, vert
 template <typename R> struct Scene {
     const Op<R>* ops; int32_t n_ops;
     const Prim<R>* prims; int32_t n_prims;
-    const TriShade<R>* tris;          // n_prims entries or null when the scene has no triangles
+    const TriShade<R>* tris;          // n_prims entries, or null when the scene has neither triangles nor boxes
     const Mat<R>* mats;
     const Tex<R>* texs;
     const uint8_t* pixels;
@@ -298,6 +299,12 @@ template <typename R> __device__ inline bool tri_t(const Prim<R>& p, const Ray<R
     return true;
 }
 
+// box under rotatey / translate (primitive.hpp:399-458, transform.hpp:9-121): the ray goes into the box's frame, the six rects are
+// tested in the constructor's order through group::intersect's shrinking t_max (group.hpp:68-83), and the record comes back
+// out through both wrappers' set_face_normal calls.  h == nullptr: distance only.
+template <typename R> struct Hit;
+template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h);
+
 // A ray that starts ON a sphere has the roots t = 0 and t = -2 (oc.d)/(d.d) exactly.  In fp64 the reference's t = 0
 // root comes out ~1e-16 and is cut by t_min = 1e-3; in fp32 the origin is only within ~1e-7 of the surface, and at
 // grazing angles c/q grows past t_min: the ray would re-hit its own sphere from the inside (measured: +3.6 % rays,
@@ -313,11 +320,11 @@ __device__ inline bool sphere_from_surface(const vec3<float>& center, const Ray<
     return true;
 }
 
-template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t)
+template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriShade<R>* aux, const Ray<R>& r, R t_min, R t_max, R& t)
 {
     R a, b;
     if constexpr (sizeof(R) == sizeof(float)) {
-        if (p.id == r.from) {
+        if (p.id == r.from && p.kind() != RT_PRIM_BOX) {   // (a box is tested again, without the side the ray starts on: see box_t)
             if (p.kind() == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
             if (p.kind() == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
             return false;
@@ -327,6 +334,7 @@ template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const Ray<
     case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
+    case RT_PRIM_BOX: return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr);
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
@@ -384,6 +392,11 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
         set_face_normal(h, r, n);
         break;
     }
+    case RT_PRIM_BOX: {
+        R tt;
+        box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
+        break;
+    }
     default: {
         R oa, ob, ok, da, db, dk;
         plane_split(p.kind(), r.o, oa, ob, ok);
@@ -401,13 +414,85 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
     if (p.flags() & RT_PRIM_FLAG_FLIP) h.front = !h.front;
 }
 
+template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h)
+{
+    const int fl = p.flags();
+    const vec3<R> target(aux.n[0], aux.n[1], aux.n[2]);
+    const R sn = p.g[6], cs = p.g[7];
+    Ray<R> tr = r;                                                       // translate::intersect, transform.hpp:18-28
+    if (fl & RT_PRIM_FLAG_TRANSLATE) tr.o = r.o - target;
+    Ray<R> rr = tr;                                                      // rotatey::intersect, transform.hpp:81-110
+    if (fl & RT_PRIM_FLAG_ROTATEY) {
+        rr.o.x = cs * tr.o.x - sn * tr.o.z;
+        rr.o.z = sn * tr.o.x + cs * tr.o.z;
+        rr.d.x = cs * tr.d.x - sn * tr.d.z;
+        rr.d.z = sn * tr.d.x + cs * tr.d.z;
+    }
+    // the six rects of the box constructor (primitive.hpp:409-431), in its order: xy at max z, min z; xz at max y, min y; yz at max x, min x
+    auto side = [&](int i, Prim<R>& s) {
+        const int pair = i >> 1;
+        s.kf = pair == 0 ? RT_PRIM_PLANEXY : (pair == 1 ? RT_PRIM_PLANEXZ : RT_PRIM_PLANEYZ);
+        s.g[0] = pair == 2 ? p.g[1] : p.g[0]; s.g[1] = pair == 2 ? p.g[4] : p.g[3];
+        s.g[2] = pair == 0 ? p.g[1] : p.g[2]; s.g[3] = pair == 0 ? p.g[4] : p.g[5];
+        const R hi = pair == 0 ? p.g[5] : (pair == 1 ? p.g[4] : p.g[3]), lo = pair == 0 ? p.g[2] : (pair == 1 ? p.g[1] : p.g[0]);
+        s.g[4] = (i & 1) ? lo : hi;
+    };
+    // fp32: a ray that starts on this box must not find the side it starts on (its t = 0 root drifts past t_min at grazing
+    // angles), but it must find the others: the wrappers' set_face_normal calls (object-space ray against the world-space
+    // normal) can turn the shading normal into the box, and the reference then traces the path inside it.
+    const bool self = sizeof(R) == sizeof(float) && p.id == r.from;
+    R closest = t_max;
+    int hit_side = -1;
+    Prim<R> s;
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) {                                        // group::intersect, group.hpp:68-83
+        side(i, s);
+        if (self) {
+            R oa, ob, ok;
+            plane_split(s.kind(), rr.o, oa, ob, ok);
+            const R scale = rt_abs(ok) > rt_abs(s.g[4]) ? rt_abs(ok) : rt_abs(s.g[4]);
+            if (rt_abs(s.g[4] - ok) <= R(2e-6) * (scale > R(1) ? scale : R(1))) continue;
+        }
+        R tt, a, b;
+        if (plane_t(s, rr, t_min, closest, tt, a, b)) { closest = tt; hit_side = i; }
+    }
+    if (hit_side < 0) return false;
+    t = closest;
+    if (h) {
+        side(hit_side, s);
+        R oa, ob, ok, da, db, dk;
+        plane_split(s.kind(), rr.o, oa, ob, ok);
+        plane_split(s.kind(), rr.d, da, db, dk);
+        h->t = t;
+        h->u = ((oa + t * da) - s.g[0]) / (s.g[1] - s.g[0]);
+        h->v = ((ob + t * db) - s.g[2]) / (s.g[3] - s.g[2]);
+        const int pair = hit_side >> 1;
+        set_face_normal(*h, rr, vec3<R>(pair == 2 ? R(1) : R(0), pair == 1 ? R(1) : R(0), pair == 0 ? R(1) : R(0)));
+        h->pos = rr.o + t * rr.d;
+        if (fl & RT_PRIM_FLAG_ROTATEY) {                                 // transform.hpp:99-110
+            vec3<R> position = h->pos, normal = h->normal;
+            position.x = cs * h->pos.x + sn * h->pos.z;
+            position.z = -sn * h->pos.x + cs * h->pos.z;
+            normal.x = cs * h->normal.x + sn * h->normal.z;
+            normal.z = -sn * h->normal.x + cs * h->normal.z;
+            h->pos = position;
+            set_face_normal(*h, rr, normal);
+        }
+        if (fl & RT_PRIM_FLAG_TRANSLATE) {                               // transform.hpp:25-27
+            h->pos = h->pos + target;
+            set_face_normal(*h, tr, h->normal);
+        }
+    }
+    return true;
+}
+
 struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; uint32_t w_node, w_leaf, w_bounce; };   // w_*: wave-level loop iterations (counted by the first active lane)
 __device__ inline bool first_active_lane() { return (int) __lane_id() == __ffsll((unsigned long long) __ballot(1)) - 1; }
 
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
 template <typename R, int kStats>   // 0: none, 1: count box/leaf tests, 2: counts + visit-order hash
-__device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const Ray<R>& r,
-                                  R& t_hit, VisitStats* st)
+__device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const TriShade<R>* __restrict__ aux,
+                                  const Ray<R>& r, R& t_hit, VisitStats* st)
 {
     R closest = rt_inf<R>();
     const R t_min = consts<R>::tmin;
@@ -423,7 +508,7 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
         else {
             if (kStats) st->n_leaf++;
             R t;
-            if (prim_t(prims[op.prim], r, t_min, closest, t)) { closest = t; hit = op.prim; }
+            if (prim_t(prims[op.prim], aux, r, t_min, closest, t)) { closest = t; hit = op.prim; }
             i++;
         }
     }
@@ -450,8 +535,8 @@ __device__ inline void slab2(const float* b, const vec3<float>& o, const vec3<fl
 }
 
 template <int kStats>
-__device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, const Ray<float>& r, float& t_hit,
-                                      uint32_t* stack, VisitStats* st)
+__device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, const TriShade<float>* __restrict__ aux,
+                                      const Ray<float>& r, float& t_hit, uint32_t* stack, VisitStats* st)
 {
     const float t_min = consts<float>::tmin;
     float closest = rt_inf<float>();
@@ -487,7 +572,7 @@ __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Pri
             float t;
             if (kStats && first_active_lane()) st->w_leaf++;
             if (kStats) st->n_leaf++;
-            if (prim_t(prims[first + k], r, t_min, closest, t)) { closest = t; hit = first + k; }
+            if (prim_t(prims[first + k], aux, r, t_min, closest, t)) { closest = t; hit = first + k; }
         }
         cur = (int32_t) stack[sp * 256]; sp--;
     }
@@ -838,8 +923,8 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
             if (kCount && first_active_lane()) vs.w_bounce++;
             R t;
             int prim;
-            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs);
-            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, ray, t, &vs);
+            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.tris, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs);
+            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, sc.tris, ray, t, &vs);
             bool done = true;
             if (prim >= 0) {
                 Hit<R> h;
@@ -935,7 +1020,7 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
     r.time = R(p[6]);
     VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL; st.w_node = st.w_leaf = st.w_bounce = 0;
     R t;
-    int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, r, t, &st);
+    int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, sc.tris, r, t, &st);
     prim[idx] = hit;
     t_out[idx] = hit >= 0 ? (double) t : 0.0;
     int f = -1;
@@ -962,7 +1047,7 @@ __global__ void __launch_bounds__(256) first_hit_fast_kernel(Scene<float> sc, co
     r.d = vec3<float>((float) p[3], (float) p[4], (float) p[5]);
     r.time = (float) p[6];
     float t;
-    int hit = closest_hit_bvh<0>(sc.bnodes, sc.fprims, r, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, nullptr);
+    int hit = closest_hit_bvh<0>(sc.bnodes, sc.fprims, sc.tris, r, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, nullptr);
     prim[idx] = hit >= 0 ? sc.fprims[hit].id : -1;
     t_out[idx] = hit >= 0 ? t : 0.0f;
 }

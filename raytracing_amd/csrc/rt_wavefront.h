@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, RT_WF_EXTEND_WAVES) wf_extend_kernel(Scen
                 float t;
                 if (kCount && first_active_lane()) vs.w_leaf++;
                 if (kCount) vs.n_leaf++;
-                if (prim_t(fprims[first + k], ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
+                if (prim_t(fprims[first + k], sc.tris, ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
             }
             tv.cur = (int32_t) pop(tv.sp); tv.sp--;
         }

@@ -102,11 +102,11 @@ int validate(const rt_scene_desc* d)
     for (int i = 0; i < d->n_roots; i++) if (!code_ok(d->roots[i])) return fail(RT_EINVAL, "root code out of range");
     for (int i = 0; i < 2 * d->n_nodes; i++) if (!code_ok(d->node_child[i])) return fail(RT_EINVAL, "bvh child code out of range");
     for (int i = 0; i < d->n_prims; i++) {
-        if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_TRIANGLE) return fail(RT_EINVAL, "unknown primitive kind");
+        if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown primitive kind");
         if (d->prim_mat[i] < 0 || d->prim_mat[i] >= d->n_mats) return fail(RT_EINVAL, "primitive material index out of range");
     }
     for (int i = 0; i < d->n_lights; i++)
-        if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_TRIANGLE) return fail(RT_EINVAL, "unknown light kind");
+        if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown light kind");
     for (int i = 0; i < d->n_mats; i++) {
         int k = d->mat_kind[i], t = d->mat_tex[i];
         if (k < RT_MAT_LAMBERTIAN || k > RT_MAT_PHONG) return fail(RT_EINVAL, "unknown material kind");
@@ -172,10 +172,11 @@ template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int k
 {
     std::memset(&p, 0, sizeof p);
     p.kf = kind | (flags << 8); p.mat = mat; p.id = id;
-    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : 5;
+    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : kind == RT_PRIM_BOX ? 8 : 5;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
     if (tri) {
         std::memset(tri, 0, sizeof *tri);
+        if (kind == RT_PRIM_BOX) for (int k = 0; k < 3; k++) tri->n[k] = (R) g[8 + k];   // translate target
         if (kind == RT_PRIM_TRIANGLE) {
             for (int k = 0; k < 9; k++) tri->n[k] = (R) g[9 + k];
             for (int k = 0; k < 6; k++) tri->uv[k] = (R) g[18 + k];
@@ -198,6 +199,17 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
             if (!std::isfinite(f)) f = 0;
             double c[3] = { g[0] + f * (g[3] - g[0]), g[1] + f * (g[4] - g[1]), g[2] + f * (g[5] - g[2]) };
             sphere(c, std::fabs(g[8]));
+        }
+        break;
+    }
+    case RT_PRIM_BOX: {   // the eight corners, out of the box's frame: rotatey (transform.hpp:60-66) then translate
+        const int fl = d->prim_flags[i];
+        const double sn = (fl & RT_PRIM_FLAG_ROTATEY) ? g[6] : 0.0, cs = (fl & RT_PRIM_FLAG_ROTATEY) ? g[7] : 1.0;
+        for (int c = 0; c < 8; c++) {
+            const double x = (c & 1) ? g[3] : g[0], y = (c & 2) ? g[4] : g[1], z = (c & 4) ? g[5] : g[2];
+            double p[3] = { cs * x + sn * z, y, -sn * x + cs * z };
+            if (fl & RT_PRIM_FLAG_TRANSLATE) for (int k = 0; k < 3; k++) p[k] += g[8 + k];
+            b.grow(p);
         }
         break;
     }
@@ -269,9 +281,9 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         ops[i].skip = f.op_skip[i]; ops[i].prim = f.op_prim[i];
     }
     bool has_tri = false;
-    for (int i = 0; i < d->n_prims; i++) has_tri |= d->prim_kind[i] == RT_PRIM_TRIANGLE;
+    for (int i = 0; i < d->n_prims; i++) has_tri |= d->prim_kind[i] == RT_PRIM_TRIANGLE || d->prim_kind[i] == RT_PRIM_BOX;   // kinds with a side record
     bool light_tri = false;
-    for (int i = 0; i < d->n_lights; i++) light_tri |= d->light_kind[i] == RT_PRIM_TRIANGLE;
+    for (int i = 0; i < d->n_lights; i++) light_tri |= d->light_kind[i] == RT_PRIM_TRIANGLE || d->light_kind[i] == RT_PRIM_BOX;
 
     std::vector<rt::Prim<R>> prims(d->n_prims);
     std::vector<rt::TriShade<R>> tris(has_tri ? d->n_prims : 0);

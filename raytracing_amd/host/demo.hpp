@@ -69,3 +69,29 @@ inline group deep_bounce_scene()
     grp.add(new sphere(vec3d(4, 1, 0), 1.0, new metal(vec3d(0.7, 0.6, 0.5), 0)));
     return group(new bvh(grp, 0, 1));
 }
+
+// the scene of the reference's main() (reference: src/cpp/demo.hpp:63-91)
+inline group cornell_box()
+{
+    group grp;
+    material* red_diffuse = new lambertian(vec3d(0.65, 0.05, 0.05));
+    material* green_diffuse = new lambertian(vec3d(0.12, 0.45, 0.15));
+    material* white_diffuse = new lambertian(vec3d(0.75, 0.75, 0.75));
+    material* area_light = new emissive(vec3d(30, 30, 30));
+    material* mirror = new metal(vec3d(1, 1, 1), 0);
+    grp.add(new planeyz(0, 555, 0, 555, 555, green_diffuse));
+    grp.add(new planeyz(0, 555, 0, 555, 0, red_diffuse));
+    grp.add(new planexz(0, 555, 0, 555, 0, white_diffuse));
+    grp.add(new planexz(0, 555, 0, 555, 555, white_diffuse));
+    grp.add(new planexy(0, 555, 0, 555, 555, white_diffuse));
+    grp.add(new flip(new planexz(213, 343, 227, 332, 554, area_light)));
+    object* box1 = new box(vec3d(0, 0, 0), vec3d(165, 330, 165), mirror);
+    box1 = new rotatey(box1, 15);
+    box1 = new translate(box1, vec3d(265, 0, 295));
+    grp.add(box1);
+    object* box2 = new box(vec3d(0, 0, 0), vec3d(165, 165, 165), white_diffuse);
+    box2 = new rotatey(box2, -18);
+    box2 = new translate(box2, vec3d(130, 0, 65));
+    grp.add(box2);
+    return grp;
+}

@@ -90,3 +90,20 @@ public:
     bool bounding_box(double, double, aabb& bbox) const override { bbox = aabb(vec3d(k - 0.001, y0, z0), vec3d(k + 0.001, y1, z1)); return true; }
     bool leaf_record(flat_leaf& out) const override { return record(out, y0, y1, z0, z1, k); }
 };
+
+// box: six rects tested as one object (reference: src/cpp/primitive.hpp:399-458).  One leaf of the bvh; the HIP core walks the
+// sides in the constructor's order (xy at max z, min z; xz at max y, min y; yz at max x, min x).
+class box : public object {
+public:
+    vec3d minimum, maximum;
+    material* mat;
+    box(const vec3d& mn, const vec3d& mx, material* m) : minimum(mn), maximum(mx), mat(m) {}
+    bool bounding_box(double, double, aabb& bbox) const override { bbox = aabb(minimum, maximum); return true; }
+    bool leaf_record(flat_leaf& out) const override
+    {
+        out.kind = RT_PRIM_BOX; out.mat = mat;
+        for (int k = 0; k < 3; k++) { out.data[k] = minimum[k]; out.data[3 + k] = maximum[k]; }
+        out.data[6] = 0.0; out.data[7] = 1.0;
+        return true;
+    }
+};

@@ -98,6 +98,23 @@ rth_scene* rth_build_mixed(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// the reference's own main() scene: raytracing.cpp:77-88 (Cornell box, camera at (278,278,-800), one flipped rect light)
+rth_scene* rth_build_cornell(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        camera cam = camera(vec3d(278, 278, -800), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, 1, 0, 1, 0, 1);
+        object* light = new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30))));
+        scene scn(width, height);
+        scn.add_object(cornell_box());
+        scn.add_light(light);
+        scn.set_camera(cam);
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
 // BASELINE config 4: deep_bounce_scene() (demo.hpp) under the same light and camera as the random-spheres configs
 rth_scene* rth_build_deep_bounce(int width, int height, unsigned seed)
 {

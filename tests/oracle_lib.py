@@ -33,7 +33,8 @@ def lib():
         L.orc_scene_new.restype = C.c_void_p
         L.orc_build_c0.restype = C.c_void_p
         L.orc_build_mixed.restype = C.c_void_p
-        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed"):
+        L.orc_build_cornell.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         _lib = L
     return _lib
@@ -62,6 +63,11 @@ class Scene:
     @classmethod
     def mixed(cls, width, height, seed=1):
         return cls(lib().orc_build_mixed(width, height, seed), width, height)
+
+    @classmethod
+    def cornell(cls, width, height, seed=1):
+        """the scene of the reference's main(): raytracing.cpp:77-88 over cornell_box() (demo.hpp:63-91)"""
+        return cls(lib().orc_build_cornell(width, height, seed), width, height)
 
     def free(self):
         if self.h:

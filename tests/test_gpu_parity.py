@@ -18,6 +18,7 @@ SCENES = {
     "c0_seed1": ("c0", lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "c0_seed7": ("c0", lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "mixed": ("mixed", lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
+    "cornell": ("cornell", lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
     "obj": ("obj", lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 
@@ -65,8 +66,11 @@ def test_first_hit_bit_exact_vs_reference_fixture(R, golden_dir, name):
 def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
     """RT_MODE_FAST_FP32 walks the library's own SAH tree in fp32; the closest hit must still be the reference's.
     Bar: same primitive id on >= 99.9 % of the fixture rays (fp32 rounding may swap two hits closer than ~1e-6, or
-    lose a grazing hit), t within 2e-4 relative on the agreeing rays.  Rays with a zero direction component are the
-    fixture's NaN-slab edge cases for the fp64 parity walk and are left out here."""
+    lose a grazing hit), t within 2e-4 relative on the agreeing rays.  Where two surfaces coincide (the Cornell box: a
+    box's bottom face lies in the floor plane, walls meet the floor along the exact diagonal of the pixel-centre rays)
+    the reference's answer is decided by its visit order; a different primitive at the same t counts as the same hit.
+    Rays with a zero direction component are the fixture's NaN-slab edge cases for the fp64 parity walk and are left
+    out here."""
     tag, make = SCENES[name]
     g, m = load(golden_dir, name)
     osc = make(golden_dir, m)
@@ -77,7 +81,10 @@ def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
     want = np.where(entry >= 0, ids[np.maximum(entry, 0)], -1)
     keep = np.all(np.abs(rays[:, 3:6]) > 1e-200, axis=1)
     out = sc.first_hit_fast(rays)
-    same = out["prim"][keep] == want[keep]
+    tref_all = g[tag + "_fh_t"]
+    with np.errstate(invalid="ignore"):
+        coincident = (out["prim"] >= 0) & (want >= 0) & (np.abs(out["t"] - tref_all) <= 2e-6 * np.abs(tref_all))
+    same = ((out["prim"] == want) | coincident)[keep]
     assert same.mean() >= 0.999, f"{(~same).sum()} of {keep.sum()} rays hit a different primitive"
     hit = keep & (want >= 0) & (out["prim"] == want)
     tref = g[tag + "_fh_t"][hit]
@@ -86,7 +93,7 @@ def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
     osc.free()
 
 
-@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "obj"])
+@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "cornell", "obj"])
 def test_render_fp64_matches_oracle_same_streams(R, golden_dir, name):
     tag, make = SCENES[name]
     g, m = load(golden_dir, name)
@@ -110,7 +117,7 @@ def test_render_fp64_matches_oracle_same_streams(R, golden_dir, name):
 
 
 @pytest.mark.parametrize("mode_name", ["fast", "reftree", "fast_lanesync", "fast_wavefront"])
-@pytest.mark.parametrize("name,early", [("c0_seed1", 0), ("obj", 0), ("c0_seed1", 1), ("mixed", 1), ("obj", 1)])
+@pytest.mark.parametrize("name,early", [("c0_seed1", 0), ("obj", 0), ("cornell", 0), ("c0_seed1", 1), ("mixed", 1), ("obj", 1)])
 def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name):
     """fp32 modes (fast = own SAH tree, per-wave traverse/shade/regenerate state machine; fast_lanesync and fast_wavefront = the
     same tree and arithmetic through the lane-synchronous loop and through the multi-kernel wavefront pipeline; reftree =

@@ -32,6 +32,7 @@ SCENES = {
     "c0_seed1": ("c0", 48, lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "c0_seed7": ("c0", 48, lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "mixed": ("mixed", 32, lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
+    "cornell": ("cornell", 48, lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
     "obj": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 
