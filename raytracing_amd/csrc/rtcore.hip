@@ -78,7 +78,7 @@ struct rt_scene {
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
     std::vector<void*> wf_owned;
     uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
-    uint32_t trav_keep = 96, node_keep = 128, regen_min = 8;   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
+    uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
@@ -427,6 +427,9 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
     if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
     if (const char* env = std::getenv("RT_WF_SLOTS")) s->wf_slots = (uint32_t) std::min(64ll << 20, std::max(256ll, std::atoll(env)));
+    // measured optima (tools/sweep_wave.py, 4K): small scenes spend as much time shading as traversing and want fuller shading
+    // passes (64/64); big meshes are traversal-bound and want fuller node steps (96/128)
+    if (desc->n_prims < 4096) { s->trav_keep = 64; s->node_keep = 64; }
     if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));

@@ -1,9 +1,11 @@
 // raytracing_amd/host/render_image.cpp -- the reference's driver (src/cpp/raytracing.cpp:73-137) on the GPU core:
 // same scene-building statements, the pixel/sample loop replaced by scene::render().
-//   render_image [out.png] [width height spp max_depth] [scene.obj]
+//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell]
+// `render_image output.png 1024 1024 100 10 cornell` is the reference's own main() (raytracing.cpp:77-90,132-137).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "rt_host.hpp"
 
@@ -14,7 +16,12 @@ int main(int argc, char* argv[])
     int spp = argc > 4 ? std::atoi(argv[4]) : 10, max_depth = argc > 5 ? std::atoi(argv[5]) : 50;
 
     scene scn(width, height);
-    if (argc > 6) {
+    if (argc > 6 && !std::strcmp(argv[6], "cornell")) {
+        scn.add_object(cornell_box());
+        scn.add_light(new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30)))));
+        scn.set_camera(camera(vec3d(278, 278, -800), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, 1, 0, 1, 0, 1));
+    }
+    else if (argc > 6) {
         loader obj_loader(argv[6]);
         scn.add_object(obj_loader.meshes());
         scn.add_light(*obj_loader.lights());

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librtcore.so")
+LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(HERE, "librtcore.so")   # RTCORE_LIB: A/B builds of the same library (tools/)
 
 MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE = 0, 1, 2
 FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_LEGACY_LOOP, FLAG_WAVEFRONT = 1, 2, 4, 8, 16, 32
