@@ -657,29 +657,31 @@ template <typename R> __device__ inline vec3<R> cosine_sample(Rng& g, const vec3
     return (rc.x * a0 + rc.y * a1) + rc.z * a2;
 }
 
-template <typename R> __device__ inline vec3<R> mat_emit(const Scene<R>& sc, const Mat<R>& m, const Hit<R>& h)
+// `texc`: the material's texture evaluated at the hit (tex_color draws no random numbers, so it is evaluated once, before the
+// per-material branches, for every lane whose material has one: one copy of the texture code, executed by all of them together)
+template <typename R> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const Hit<R>& h, const vec3<R>& texc)
 {
-    if (m.kind == RT_MAT_EMISSIVE) return h.front ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();                 // material.hpp:146-154
+    if (m.kind == RT_MAT_EMISSIVE) return h.front ? texc : vec3<R>();                                                   // material.hpp:146-154
     if (m.kind == RT_MAT_PHONG) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
     return vec3<R>();
 }
 
 // material::shading.  wo keeps its default (origin 0, direction 0, time 0: `ray wo;` raytracing.cpp:41) when the
 // material does not set it (phong's specular and diffuse branches).
-template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h,
+template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
                                                          Ray<R>& wo, vec3<R>& att, bool& spec)
 {
     switch (m.kind) {
     case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
         spec = false;
         wo.o = h.pos; wo.from = h.id; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
-        att = tex_color(sc, m.tex, h.pos, h.u, h.v);
+        att = texc;
         return true;
     case RT_MAT_METAL: {                                                                    // material.hpp:74-82
         vec3<R> next = reflect(normalize(wi.d), h.normal);
         vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
         wo.o = h.pos; wo.from = h.id; wo.d = next + fuzz; wo.time = wi.time;
-        att = tex_color(sc, m.tex, h.pos, h.u, h.v);
+        att = texc;
         spec = true;
         return true;
     }
@@ -690,7 +692,7 @@ template <typename R> __device__ inline bool mat_shading(const Scene<R>& sc, Rng
         return true;
     case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
-        vec3<R> base = (m.tex >= 0) ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>(m.d[1], m.d[2], m.d[3]);
+        vec3<R> base = (m.tex >= 0) ? texc : vec3<R>(m.d[1], m.d[2], m.d[3]);
         if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
             att = vec3<R>(m.d[4], m.d[5], m.d[6]);
             spec = true;
@@ -930,12 +932,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
                 Hit<R> h;
                 fill_record(kTrav == 2 ? sc.fprims[prim] : prims[prim], sc.tris, ray, t, sc.need_uv != 0, h);
                 const Mat<R>& m = sc.mats[h.mat];
-                vec3<R> emission = mat_emit(sc, m, h);
+                const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
+                vec3<R> emission = mat_emit(m, h, texc);
                 Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
                 vec3<R> att;
                 bool spec = false;
                 L += beta * emission;
-                if (mat_shading(sc, g, m, ray, h, wo, att, spec)) {
+                if (mat_shading(g, m, ray, h, texc, wo, att, spec)) {
                     R pdf, mpdf;
                     if (spec) {                                                             // raytracing.cpp:51-54
                         mpdf = mat_pdf(g, m, h, wo);

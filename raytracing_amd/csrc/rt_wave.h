@@ -182,12 +182,13 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                 Hit<float> h;
                 fill_record(fprims[tv.hit], sc.tris, ray, tv.closest, sc.need_uv != 0, h);
                 const Mat<float>& m = sc.mats[h.mat];
-                vec3<float> emission = mat_emit(sc, m, h);
+                const vec3<float> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<float>();
+                vec3<float> emission = mat_emit(m, h, texc);
                 Ray<float> wo; wo.time = 0.f;                                               // `ray wo;` raytracing.cpp:41
                 vec3<float> att;
                 bool spec = false;
                 L += beta * emission;
-                if (mat_shading(sc, g, m, ray, h, wo, att, spec)) {
+                if (mat_shading(g, m, ray, h, texc, wo, att, spec)) {
                     float pdf, mpdf;
                     if (spec) {                                                             // raytracing.cpp:51-54
                         mpdf = mat_pdf(g, m, h, wo);
