@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (split over the ranks)")
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--mode", choices=["fp32", "fp32ref", "fp64"], default="fp32", help="fp32: fast SAH tree; fp32ref: reference tree in fp32; fp64: reference mode")
-    ap.add_argument("--workload", choices=["obj", "random_spheres"], default="obj", help="obj: BASELINE configs[2] (the config the metric is quoted on); random_spheres: configs[1]")
+    ap.add_argument("--workload", choices=["obj", "random_spheres", "soup"], default="obj", help="obj: BASELINE configs[2] (the config the metric is quoted on); random_spheres: configs[1]; soup: configs[3] (triangle soup with image textures)")
+    ap.add_argument("--soup-tris", type=int, default=10_000_000)
+    ap.add_argument("--soup-tex", type=int, default=1024, help="edge of each of the 64 map_Kd textures")
     ap.add_argument("--obj", default="auto", help="OBJ file of the obj workload; auto = generate the procedural mesh (raytracing_amd/tools/make_mesh.py)")
     ap.add_argument("--mesh-level", type=int, default=8, help="icosphere subdivision of the generated mesh: 8 -> 1.31 M triangles")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -107,6 +109,14 @@ def main():
     if args.workload == "random_spheres":
         host = HostScene.random_spheres(w, h, 1)
         workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
+    elif args.workload == "soup":
+        from raytracing_amd.tools.make_mesh import write_soup
+        obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_soup_{args.soup_tris}_r{rank}.obj")
+        write_soup(obj_path, args.soup_tris, 64, args.soup_tex)
+        host = HostScene.obj(obj_path, w, h, 1, cam_pos=(0, 5.0, 75.0), cam_lookat=(0, 0, 0), fov=40.0)
+        n_tri = int(host.desc.contents.n_prims)
+        workload = (f"BASELINE configs[3]: {n_tri}-triangle soup in [-50,50]^3, 64 MTL materials each with a {args.soup_tex}^2 PNG map_Kd, emissive quad, "
+                    f"through the OBJ loader and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
     else:
         obj_path = args.obj
         if obj_path == "auto":
@@ -184,7 +194,7 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                rec = json.load(f).get(f"{args.workload}:{args.mode}:{w}x{h}:d{args.depth}")
+                rec = json.load(f).get(f"{args.workload}:{int(d.n_prims)}:{args.mode}:{w}x{h}:d{args.depth}")
             if rec:
                 traffic = int(rec["bytes_per_ray"] * rays_per_launch)
         except (OSError, ValueError):
@@ -213,7 +223,7 @@ def main():
             "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
                        "parallelism": f"spp split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
-                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp},
+                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu:

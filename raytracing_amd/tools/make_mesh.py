@@ -77,6 +77,57 @@ def write_scene(path, level=8, seed=12345):
     return len(f) + 4
 
 
+def _write_png(path, rgb):
+    """8-bit RGB PNG (zlib + CRC only: no imaging library in the image)."""
+    import struct
+    import zlib
+    h, w, _ = rgb.shape
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rgb.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+
+
+def write_soup(path, n_tri=10_000_000, n_mats=64, tex_size=1024, extent=50.0, edge=0.2, seed=12345):
+    """BASELINE configs[3]: a triangle soup (uniform random centres in [-extent, extent]^3, edge ~`edge`) with `n_mats` MTL
+    materials, each with its own procedural `tex_size`^2 PNG map_Kd, per-vertex uvs, under one emissive quad.  Incoherent,
+    far larger than the caches: the node / primitive / texel fetch stress case."""
+    rng = np.random.default_rng(seed)
+    d = os.path.dirname(os.path.abspath(path))
+    base = os.path.splitext(os.path.basename(path))[0]
+    yy, xx = np.mgrid[0:tex_size, 0:tex_size]
+    with open(os.path.splitext(path)[0] + ".mtl", "w") as m:
+        for k in range(n_mats):
+            img = np.stack([(xx * (k + 3) // 7 + yy) & 255, (yy * (k + 5) // 9 + 3 * k) & 255, ((xx ^ yy) + 11 * k) & 255], axis=2).astype(np.uint8)
+            _write_png(os.path.join(d, f"{base}_t{k}.png"), img)
+            m.write(f"newmtl m{k}\nKd 0.7 0.7 0.7\nmap_Kd {base}_t{k}.png\n\n")
+        m.write("newmtl lamp\nKd 0.0 0.0 0.0\nKe 40.0 40.0 40.0\n")
+    c = rng.uniform(-extent, extent, size=(n_tri, 3))
+    p = c[:, None, :] + rng.normal(scale=edge * 0.5, size=(n_tri, 3, 3))
+    uv = rng.uniform(0, 1, size=(n_tri * 3, 2))
+    per = n_tri // n_mats
+    with open(path, "w") as o:
+        o.write(f"mtllib {base}.mtl\no soup\n")
+        np.savetxt(o, p.reshape(-1, 3), fmt="v %.5f %.5f %.5f")
+        np.savetxt(o, uv, fmt="vt %.5f %.5f")
+        idx = np.arange(1, n_tri * 3 + 1).reshape(-1, 3)
+        for k in range(n_mats):
+            g = idx[k * per:(k + 1) * per if k < n_mats - 1 else n_tri]
+            o.write(f"usemtl m{k}\n")
+            np.savetxt(o, np.stack([g[:, 0], g[:, 0], g[:, 1], g[:, 1], g[:, 2], g[:, 2]], 1), fmt="f %d/%d %d/%d %d/%d")
+        nv = n_tri * 3
+        e = extent * 1.2
+        o.write("o lamp\nusemtl lamp\n")
+        for q in [(-e, extent * 1.3, -e), (e, extent * 1.3, -e), (e, extent * 1.3, e), (-e, extent * 1.3, e)]:
+            o.write("v %.5f %.5f %.5f\n" % q)
+        o.write("vn 0 -1 0\n")
+        o.write("f %d//1 %d//1 %d//1\nf %d//1 %d//1 %d//1\n" % (nv + 1, nv + 2, nv + 3, nv + 1, nv + 3, nv + 4))
+    return n_tri + 2
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("out")

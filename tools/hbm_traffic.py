@@ -35,7 +35,7 @@ w_kb = sorted(x[1] for x in full)[len(full) // 2]
 bytes_per_launch = f_kb * 1024 * 2 + w_kb * 1024
 cfg = bench["config"]
 mode = {"f32": "fp32", "f64": "fp64"}[bench["dtype"]]
-key = f"{'obj' if 'OBJ' in cfg['workload'] else 'random_spheres'}:{mode}:{cfg['width']}x{cfg['height']}:d{cfg['max_depth']}"
+key = f"{'obj' if 'OBJ' in cfg['workload'] else 'random_spheres'}:{cfg['n_primitives']}:{mode}:{cfg['width']}x{cfg['height']}:d{cfg['max_depth']}"
 try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
