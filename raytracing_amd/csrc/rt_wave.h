@@ -51,7 +51,34 @@ __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, floa
     hit = tn <= fmaf(tf, 1.0000004f, t.slack);     // conservative under fp32 rounding
 }
 
-template <bool kCount>
+// both children of a quantised node: per axis t = q * (step * idir) + (origin * idir - o * idir)
+__device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
+{
+    float x[4], y[4], z[4];
+    {
+        const float A = __uint_as_float((n.o[0] & 0xffu) << 23) * t.idir.x, B = fmaf(__uint_as_float(n.o[0] & 0xffffff00u), t.idir.x, t.noid.x);
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = fmaf(float((n.q[0] >> (8 * k)) & 0xffu), A, B);
+    }
+    {
+        const float A = __uint_as_float((n.o[1] & 0xffu) << 23) * t.idir.y, B = fmaf(__uint_as_float(n.o[1] & 0xffffff00u), t.idir.y, t.noid.y);
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k] = fmaf(float((n.q[1] >> (8 * k)) & 0xffu), A, B);
+    }
+    {
+        const float A = __uint_as_float((n.o[2] & 0xffu) << 23) * t.idir.z, B = fmaf(__uint_as_float(n.o[2] & 0xffffff00u), t.idir.z, t.noid.z);
+#pragma unroll
+        for (int k = 0; k < 4; k++) z[k] = fmaf(float((n.q[2] >> (8 * k)) & 0xffu), A, B);
+    }
+    const float tnl = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), t_min));
+    const float tfl = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), t.closest));
+    const float tnr = fmaxf(fmaxf(fminf(x[2], x[3]), fminf(y[2], y[3])), fmaxf(fminf(z[2], z[3]), t_min));
+    const float tfr = fminf(fminf(fmaxf(x[2], x[3]), fmaxf(y[2], y[3])), fminf(fmaxf(z[2], z[3]), t.closest));
+    tl = tnl; hl = tnl <= fmaf(tfl, 1.0000004f, t.slack);
+    tr = tnr; hr = tnr <= fmaf(tfr, 1.0000004f, t.slack);
+}
+
+template <bool kCount, bool kQuant>
 __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
@@ -139,21 +166,30 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                 const int n_inner = __popcll(__ballot(tv.cur >= 0));
                 if (n_inner == 0 || n_inner * 256 < n_trav * node_keep) break;
                 if (tv.cur >= 0) {
-                    const BNode n = nodes[tv.cur];
-                    if (kCount && first_active_lane()) vs.w_node++;
                     float tl, tr; bool hl, hr;
-                    slab_fma(n.lb, tv, t_min, tl, hl);
-                    slab_fma(n.rb, tv, t_min, tr, hr);
+                    int32_t c_left, c_right;
+                    if (kQuant) {
+                        const QNode n = sc.qnodes[tv.cur];
+                        slab_quant(n, tv, t_min, tl, hl, tr, hr);
+                        c_left = n.left; c_right = n.right;
+                    }
+                    else {
+                        const BNode n = nodes[tv.cur];
+                        slab_fma(n.lb, tv, t_min, tl, hl);
+                        slab_fma(n.rb, tv, t_min, tr, hr);
+                        c_left = n.left; c_right = n.right;
+                    }
+                    if (kCount && first_active_lane()) vs.w_node++;
                     if (kCount) vs.n_box += 2;
                     if (hl && hr) {
                         const bool left_first = tl <= tr;
-                        const int32_t far = left_first ? n.right : n.left;
-                        tv.cur = left_first ? n.left : n.right;
+                        const int32_t far = left_first ? c_right : c_left;
+                        tv.cur = left_first ? c_left : c_right;
                         tv.sp++;
                         stack[tv.sp * 256] = (uint32_t) far;
                     }
-                    else if (hl) tv.cur = n.left;
-                    else if (hr) tv.cur = n.right;
+                    else if (hl) tv.cur = c_left;
+                    else if (hr) tv.cur = c_right;
                     else { tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--; }
                 }
             }

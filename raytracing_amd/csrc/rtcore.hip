@@ -78,7 +78,8 @@ struct rt_scene {
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
     std::vector<void*> wf_owned;
     uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
-    uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
+    uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;
+    uint32_t quantised = 0;                   // fast mode walks the 32-byte nodes (RT_QNODES overrides)   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
@@ -237,7 +238,7 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
 
 template <typename R> int build_fast_tree(const rt_scene_desc*, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out)
 {
-    out.view.bnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
+    out.view.bnodes = nullptr; out.view.qnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
     return RT_OK;
 }
 template <> int build_fast_tree<float>(const rt_scene_desc* d, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out)
@@ -262,10 +263,41 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const std::vector
         }
         nodes[i].left = tree.nodes[i].left; nodes[i].right = tree.nodes[i].right;
     }
+    // 32-byte quantised twin of every node (rt_device.h QNode): decoded boxes must contain the fp32 boxes above
+    double radius = 0;
+    for (const rt::BNode& n : nodes) for (int k = 0; k < 6; k++) { if (std::isfinite(n.lb[k])) radius = std::max(radius, (double) std::fabs(n.lb[k])); if (std::isfinite(n.rb[k])) radius = std::max(radius, (double) std::fabs(n.rb[k])); }
+    const double pad = 8 * 1.2e-7 * std::max(radius, 1e-30);       // fp32 decode error of origin*idir - o*idir, in world units
+    std::vector<rt::QNode> qn(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const rt::BNode& n = nodes[i];
+        for (int a = 0; a < 3; a++) {
+            const double lo[2] = { (double) n.lb[a] - pad, (double) n.rb[a] - pad }, hi[2] = { (double) n.lb[3 + a] + pad, (double) n.rb[3 + a] + pad };
+            const double mn = std::min(lo[0], lo[1]), mx = std::max(hi[0], hi[1]);
+            float f = down(mn);
+            uint32_t bits; std::memcpy(&bits, &f, 4);
+            if (bits & 0xffu) bits = (bits & 0x80000000u) ? (bits | 0xffu) + 1u : (bits & ~0xffu);   // low 8 bits free, value not above mn
+            float origin_f; std::memcpy(&origin_f, &bits, 4);
+            const double origin = origin_f, ext = std::max(mx - origin, 0.0);
+            int e = (int) std::ceil(std::log2(std::max(ext / 254.0, 1e-37)));
+            while (std::ldexp(254.0, e) < ext) e++;
+            const int biased = std::min(254, std::max(1, e + 127));
+            const double step = std::ldexp(1.0, biased - 127);
+            uint32_t q = 0;
+            for (int c = 0; c < 2; c++) {
+                const double ql = std::floor((lo[c] - origin) / step), qh = std::ceil((hi[c] - origin) / step);
+                const uint32_t l8 = (uint32_t) std::min(255.0, std::max(0.0, ql)), h8 = (uint32_t) std::min(255.0, std::max(0.0, qh));
+                q |= (l8 << (16 * c)) | (h8 << (16 * c + 8));
+            }
+            qn[i].o[a] = bits | (uint32_t) biased;
+            qn[i].q[a] = q;
+        }
+        qn[i].left = n.left; qn[i].right = n.right;
+    }
     std::vector<rt::Prim<float>> ordered(tree.order.size());
     for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree.order[i]];
     int rc;
     if ((rc = upload(out.owned, nodes, &out.view.bnodes))) return rc;
+    if ((rc = upload(out.owned, qn, &out.view.qnodes))) return rc;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
     out.view.n_bnodes = (int32_t) nodes.size();
     out.view.bvh_depth = tree.depth;
@@ -430,6 +462,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     // measured optima (tools/sweep_wave.py, 4K): small scenes spend as much time shading as traversing and want fuller shading
     // passes (64/64); big meshes are traversal-bound and want fuller node steps (96/128)
     if (desc->n_prims < 4096) { s->trav_keep = 64; s->node_keep = 64; }
+    if (const char* env = std::getenv("RT_QNODES")) s->quantised = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
@@ -465,7 +498,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
-    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min;
+    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised;
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
         int rc = wf_prepare(s);
         if (rc) return rc;

@@ -175,6 +175,25 @@ def test_host_built_scenes_fp64_and_fp32_vs_oracle(R, which, depth):
     hs.free()
 
 
+def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
+    """RT_QNODES=1: the fast mode walks the 32-byte quantised twin of its tree (two vector loads per node instead of four).
+    Decoded boxes contain the real ones, so closest hits -- and with the same RNG streams the whole frame -- must not change:
+    equal ray and rejected-sample counts, sums equal up to the fp32 order of the tile additions."""
+    g, m = load(golden_dir, "obj")
+    osc = SCENES["obj"][1](golden_dir, m)
+    w, h = m["width"], m["height"]
+    frames = []
+    for q in ("0", "1"):
+        monkeypatch.setenv("RT_QNODES", q)
+        sc = R.Scene(osc.export())
+        frames.append(sc.render_to_host(w, h, 0, 16, 12, R.MODE_FAST_FP32, seed=3))
+        sc.destroy()
+    (a, _, sa), (b, _, sb) = frames
+    assert sa["rays"] == sb["rays"] and sa["rejected"] == sb["rejected"]
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+    osc.free()
+
+
 def test_resolve_matches_oracle(R):
     rng = np.random.default_rng(3)
     sums = np.concatenate([rng.uniform(0, 40, 3000), [0.0, 1e-9, 16.0, 15.999999, 1e9, 5e-324]]).reshape(-1, 3)
