@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--soup-tex", type=int, default=1024, help="edge of each of the 64 map_Kd textures")
     ap.add_argument("--obj", default="auto", help="OBJ file of the obj workload; auto = generate the procedural mesh (raytracing_amd/tools/make_mesh.py)")
     ap.add_argument("--mesh-level", type=int, default=8, help="icosphere subdivision of the generated mesh: 8 -> 1.31 M triangles")
+    ap.add_argument("--split", choices=["spp", "rows"], default="spp", help="N > 1: split the frame's samples (default) or its rows over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-spp", type=int, default=1)
     return ap.parse_args()
@@ -84,7 +85,7 @@ def main():
     import torch.distributed as dist
     import raytracing_amd as R
     from raytracing_amd.host_scenes import HostScene
-    from raytracing_amd.parallel import reduce_frame, sample_range
+    from raytracing_amd.parallel import reduce_frame, row_range, sample_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -132,13 +133,14 @@ def main():
     os.close(saved_stdout)
 
     # this rank's share of the frame's samples
-    k0, k1 = sample_range(rank, world, spp)
+    k0, k1 = sample_range(rank, world, spp) if args.split == "spp" else (0, spp)
+    y0, y1 = (0, h) if args.split == "spp" else row_range(rank, world, h)     # rows split: the other rows of `accum` stay zero, the reduce gathers
     accum = torch.zeros((h, w, 3), dtype=dtype, device="cuda")
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        st = scene.render(accum.data_ptr(), w, h, k0, k1, args.depth, mode, seed=1, stream=stream)   # syncs, returns kernel stats
+        st = scene.render(accum.data_ptr(), w, h, k0, k1, args.depth, mode, seed=1, stream=stream, y_begin=y0, y_end=y1)   # syncs, returns kernel stats
         reduce_frame(accum, world, dst=0)
         if rank == 0:
             R.resolve(accum.data_ptr(), args.mode == "fp64", w * h, spp, rgb.data_ptr(), stream=stream)
@@ -174,7 +176,7 @@ def main():
 
     if rank == 0:
         # test counts for the roofline: one diagnostic launch (counting kernel variant) on a 1-spp sample of this rank's work
-        probe = scene.render(accum.data_ptr(), w, h, k0, k0 + 1, args.depth, mode, seed=1, stream=stream, flags=R.FLAG_COUNT_TESTS)
+        probe = scene.render(accum.data_ptr(), w, h, k0, k0 + 1, args.depth, mode, seed=1, stream=stream, flags=R.FLAG_COUNT_TESTS, y_begin=y0, y_end=y1)
         box_per_ray = probe["box_tests"] / max(probe["rays"], 1)
         leaf_per_ray = probe["leaf_tests"] / max(probe["rays"], 1)
         rays_per_launch = rays / max(args.steps, 1)
@@ -222,7 +224,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.mode == "fp64" else "f32",
             "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
-                       "parallelism": f"spp split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
+                       "parallelism": f"{args.split} split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims)},
             "roofline": roofline,
         }

@@ -177,8 +177,9 @@ def test_host_built_scenes_fp64_and_fp32_vs_oracle(R, which, depth):
 
 def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     """RT_QNODES=1: the fast mode walks the 32-byte quantised twin of its tree (two vector loads per node instead of four).
-    Decoded boxes contain the real ones, so closest hits -- and with the same RNG streams the whole frame -- must not change:
-    equal ray and rejected-sample counts, sums equal up to the fp32 order of the tile additions."""
+    Decoded boxes contain the real ones, so closest hits -- and with the same RNG streams the frame -- do not change, except
+    where a ray hits the shared edge of two triangles at the same t: the winner then depends on the visit order, which the
+    inflated boxes may swap.  Bar: ray and rejected-sample counts within 0.1 %, relative RMSE of the sums < 1 %."""
     g, m = load(golden_dir, "obj")
     osc = SCENES["obj"][1](golden_dir, m)
     w, h = m["width"], m["height"]
@@ -189,8 +190,64 @@ def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
         frames.append(sc.render_to_host(w, h, 0, 16, 12, R.MODE_FAST_FP32, seed=3))
         sc.destroy()
     (a, _, sa), (b, _, sb) = frames
-    assert sa["rays"] == sb["rays"] and sa["rejected"] == sb["rejected"]
-    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+    assert abs(sa["rays"] - sb["rays"]) <= 1e-3 * sa["rays"] and abs(sa["rejected"] - sb["rejected"]) <= 1e-3 * sa["rejected"] + 2
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.01 * np.sqrt(np.mean(a ** 2))
+    osc.free()
+
+
+@pytest.mark.parametrize("name", ["c0_seed1", "cornell"])
+def test_converged_image_matches_cpu_reference_independent_streams(R, golden_dir, name):
+    """The north-star image check: a converged GPU render against a converged CPU render of the same scene and spp drawn from
+    INDEPENDENT random streams (different seeds), so nothing but the estimator has to agree.  Tolerance: the relative RMSE
+    between GPU and CPU must not exceed 1.25 x the RMSE between two CPU renders with different seeds (the Monte-Carlo noise
+    floor at this spp), and the PSNR of the 8-bit images must be within 1 dB of the CPU-vs-CPU PSNR."""
+    tag, make = SCENES[name]
+    g, m = load(golden_dir, name)
+    osc = make(golden_dir, m)
+    w, h, spp, depth = m["width"], m["height"], 512, min(m["depth"], 20)
+    a, a_rgb, _ = osc.render(0, spp, depth, O.RNG_COUNTER, seed=101, n_threads=8)
+    b, b_rgb, _ = osc.render(0, spp, depth, O.RNG_COUNTER, seed=202, n_threads=8)
+    sc = R.Scene(osc.export())
+    for mode in (R.MODE_FAST_FP32, R.MODE_REFERENCE_FP64):
+        c, c_rgb, _ = sc.render_to_host(w, h, 0, spp, depth, mode, seed=303)
+        norm = np.sqrt(np.mean(a ** 2))
+        floor = np.sqrt(np.mean((a - b) ** 2)) / norm
+        got = np.sqrt(np.mean((c - a) ** 2)) / norm
+        assert got <= 1.25 * floor, (mode, got, floor)
+
+        def psnr(x, y):
+            return 10 * np.log10(255.0 ** 2 / max(np.mean((x.astype(float) - y.astype(float)) ** 2), 1e-12))
+        assert psnr(c_rgb, a_rgb) >= psnr(b_rgb, a_rgb) - 1.0, (mode, psnr(c_rgb, a_rgb), psnr(b_rgb, a_rgb))
+    sc.destroy()
+    osc.free()
+
+
+def test_empty_work_is_well_defined(R, golden_dir):
+    """Edge cases of the sample / row / depth ranges in every kernel variant: an empty sample range, an empty row range and
+    max_depth 0 (trace() returns black at once, raytracing.cpp:32) leave zeros (or, with RT_FLAG_ACCUMULATE, the buffer
+    untouched) and count no rays."""
+    g, m = load(golden_dir, "mixed")
+    osc = SCENES["mixed"][1](golden_dir, m)
+    sc = R.Scene(osc.export())
+    w, h = 40, 24
+    for mode, variant, dt in ((R.MODE_FAST_FP32, 0, np.float32), (R.MODE_FAST_FP32, R.FLAG_LEGACY_LOOP, np.float32), (R.MODE_FAST_FP32, R.FLAG_WAVEFRONT, np.float32),
+                              (R.MODE_FP32_REFERENCE_TREE, 0, np.float32), (R.MODE_REFERENCE_FP64, 0, np.float64)):
+        acc = R.DeviceBuffer(w * h * 3 * np.dtype(dt).itemsize)
+        seven = np.full((h, w, 3), 7, dt)
+        for kw in (dict(spp=(3, 3), depth=8), dict(spp=(0, 2), depth=0), dict(spp=(0, 2), depth=8, rows=(5, 5))):
+            for flag in (0, R.FLAG_ACCUMULATE):
+                acc.upload(seven)
+                y0, y1 = kw.get("rows", (0, h))
+                st = sc.render(acc.ptr, w, h, kw["spp"][0], kw["spp"][1], kw["depth"], mode, seed=1, flags=variant | flag, y_begin=y0, y_end=y1)
+                out = acc.download(dt, (h, w, 3))
+                assert st["rays"] == 0, (mode, variant, kw, flag)
+                rows = slice(y0, y1)
+                if flag:
+                    assert np.array_equal(out, seven), (mode, variant, kw)
+                else:
+                    assert np.all(out[rows] == 0) and np.all(np.delete(out, np.arange(y0, y1), axis=0) == 7), (mode, variant, kw)
+        acc.free()
+    sc.destroy()
     osc.free()
 
 
