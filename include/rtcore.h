@@ -159,6 +159,21 @@ int rt_buffer_free(void* dev);
 int rt_buffer_download(void* host_dst, const void* dev_src, size_t bytes);
 int rt_buffer_upload(void* dev_dst, const void* host_src, size_t bytes);
 
+/* Binary scene cache (no counterpart in the reference, whose only scene source is OBJ text through tinyobj and
+ * per-triangle `new`, loader.hpp:27,124): writes / reads a flattened scene verbatim, so a 10 M-triangle scene is parsed and its
+ * reference BVH built once.  rt_scene_desc_load returns a description whose arrays live in ONE allocation owned by the
+ * library; free it with rt_scene_desc_free (after rt_scene_create, which copies what it needs).  Host only: no GPU needed. */
+int rt_scene_desc_save(const rt_scene_desc* desc, const char* path);
+int rt_scene_desc_load(const char* path, rt_scene_desc** desc_out);
+int rt_scene_desc_free(rt_scene_desc* desc);
+
+/* Progressive-accumulation checkpoint: the sample sums of a frame and how far it got.  A render is resumed by
+ * loading the sums and calling rt_render with spp_begin = *spp_done and RT_FLAG_ACCUMULATE; because RNG streams are keyed by
+ * the global sample index, the resumed frame equals the uninterrupted one (bit for bit in RT_MODE_REFERENCE_FP64).
+ * rt_checkpoint_load fails with RT_EINVAL when the file's geometry (width, height, precision) differs from the arguments. */
+int rt_checkpoint_save(const char* path, const void* accum_dev, int accum_is_fp64, int32_t width, int32_t height, int32_t spp_done, uint64_t seed);
+int rt_checkpoint_load(const char* path, void* accum_dev, int accum_is_fp64, int32_t width, int32_t height, int32_t* spp_done, uint64_t* seed);
+
 /* n draws of the counter-based stream (seed, pixel, sample), computed on the device (test hook for the RNG) */
 int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host);
 

@@ -889,6 +889,10 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
     int i, j, local = threadIdx.x;
     pixel_of(local, j, i);
     const bool own_in_image = j < a.width && i < a.y_end;
+    // lane-owned pixels (fp64 mode): RT_FLAG_ACCUMULATE continues the running sum in the buffer sample by sample, so a frame
+    // resumed from a checkpoint adds in the same order as an uninterrupted one and equals it bit for bit
+    const bool resume = !kDynamic && own_in_image && (a.flags & RT_FLAG_ACCUMULATE);
+    if (resume) { const R* in = accum + ((size_t) i * a.width + j) * 3; sum = vec3<R>(in[0], in[1], in[2]); }
 
     if (kDynamic || own_in_image) {
         uint32_t pixel = (uint32_t) (i * a.width + j);
@@ -996,7 +1000,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
     }
     if (own_in_image) {
         R* out = accum + ((size_t) i * a.width + j) * 3;
-        if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sum.x; out[1] += sum.y; out[2] += sum.z; }
+        if ((a.flags & RT_FLAG_ACCUMULATE) && !resume) { out[0] += sum.x; out[1] += sum.y; out[2] += sum.z; }
         else { out[0] = sum.x; out[1] = sum.y; out[2] = sum.z; }
     }
 

@@ -615,6 +615,144 @@ int rt_buffer_free(void* dev) { if (dev) HIP_TRY(hipFree(dev)); return RT_OK; }
 int rt_buffer_download(void* host_dst, const void* dev_src, size_t bytes) { HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost)); return RT_OK; }
 int rt_buffer_upload(void* dev_dst, const void* host_src, size_t bytes) { HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice)); return RT_OK; }
 
+// ---- binary scene cache: header, then the arrays in declaration order, each padded to 8 bytes
+namespace {
+struct CacheHeader {
+    char magic[8];                      // "RTSCENE1"
+    int32_t n_nodes, n_roots, n_prims, n_mats, n_tex, n_lights;
+    uint64_t n_pixel_bytes;
+    double camera[24];
+};
+struct CacheArray { const void* src; size_t bytes; };
+size_t pad8(size_t n) { return (n + 7) & ~(size_t) 7; }
+void cache_arrays(const rt_scene_desc* d, CacheArray a[17])
+{
+    const size_t nn = (size_t) d->n_nodes, np = (size_t) d->n_prims, nm = (size_t) d->n_mats, nt = (size_t) d->n_tex, nl = (size_t) d->n_lights;
+    const CacheArray v[17] = {
+        { d->node_bbox, nn * 6 * 8 }, { d->node_child, nn * 2 * 4 }, { d->roots, (size_t) d->n_roots * 4 },
+        { d->prim_kind, np * 4 }, { d->prim_flags, np * 4 }, { d->prim_mat, np * 4 }, { d->prim_data, np * RT_PRIM_STRIDE * 8 },
+        { d->mat_kind, nm * 4 }, { d->mat_tex, nm * 4 }, { d->mat_data, nm * RT_MAT_STRIDE * 8 },
+        { d->tex_kind, nt * 4 }, { d->tex_data, nt * RT_TEX_STRIDE * 8 }, { d->tex_pixels, d->n_pixel_bytes },
+        { d->light_kind, nl * 4 }, { d->light_flags, nl * 4 }, { d->light_mat, nl * 4 }, { d->light_data, nl * RT_PRIM_STRIDE * 8 } };
+    for (int i = 0; i < 17; i++) a[i] = v[i];
+}
+struct CheckpointHeader { char magic[8]; int32_t width, height, spp_done, is_fp64; uint64_t seed; };   // "RTCKPT01"
+}  // namespace
+
+int rt_scene_desc_save(const rt_scene_desc* d, const char* path)
+{
+    if (!path) return fail(RT_EINVAL, "path is NULL");
+    int rc = validate(d);
+    if (rc) return rc;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_EINVAL, std::string("cannot write ") + path);
+    CacheHeader h{};
+    std::memcpy(h.magic, "RTSCENE1", 8);
+    h.n_nodes = d->n_nodes; h.n_roots = d->n_roots; h.n_prims = d->n_prims; h.n_mats = d->n_mats; h.n_tex = d->n_tex; h.n_lights = d->n_lights;
+    h.n_pixel_bytes = d->n_pixel_bytes;
+    std::memcpy(h.camera, d->camera, sizeof h.camera);
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    CacheArray a[17];
+    cache_arrays(d, a);
+    const char zeros[8] = { 0 };
+    for (int i = 0; i < 17 && ok; i++) {
+        if (a[i].bytes && a[i].src) ok = std::fwrite(a[i].src, 1, a[i].bytes, f) == a[i].bytes;
+        else if (a[i].bytes) { std::fclose(f); return fail(RT_EINVAL, "a required array of the scene description is NULL"); }
+        const size_t padding = pad8(a[i].bytes) - a[i].bytes;
+        if (ok && padding) ok = std::fwrite(zeros, 1, padding, f) == padding;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : fail(RT_EINVAL, std::string("short write to ") + path);
+}
+
+int rt_scene_desc_load(const char* path, rt_scene_desc** out)
+{
+    if (!path || !out) return fail(RT_EINVAL, "path and desc_out are required");
+    *out = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(RT_EINVAL, std::string("cannot read ") + path);
+    CacheHeader h{};
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "RTSCENE1", 8) != 0 || h.n_nodes < 0 || h.n_roots <= 0 || h.n_prims <= 0 ||
+        h.n_mats <= 0 || h.n_tex < 0 || h.n_lights < 0) { std::fclose(f); return fail(RT_EINVAL, std::string(path) + " is not a scene cache"); }
+    rt_scene_desc tmp{};
+    tmp.n_nodes = h.n_nodes; tmp.n_roots = h.n_roots; tmp.n_prims = h.n_prims; tmp.n_mats = h.n_mats; tmp.n_tex = h.n_tex; tmp.n_lights = h.n_lights;
+    tmp.n_pixel_bytes = (size_t) h.n_pixel_bytes;
+    CacheArray a[17];
+    cache_arrays(&tmp, a);
+    size_t total = pad8(sizeof(rt_scene_desc));
+    for (int i = 0; i < 17; i++) total += pad8(a[i].bytes);
+    // the file must hold exactly what the header promises (a truncated or foreign file must not drive a huge allocation)
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, (long) sizeof h, SEEK_SET);
+    if (size < 0 || (size_t) size != sizeof h + total - pad8(sizeof(rt_scene_desc))) { std::fclose(f); return fail(RT_EINVAL, std::string(path) + ": size does not match its header"); }
+    char* block = static_cast<char*>(std::malloc(total));
+    if (!block) { std::fclose(f); return fail(RT_ENOMEM, "out of host memory"); }
+    rt_scene_desc* d = reinterpret_cast<rt_scene_desc*>(block);
+    *d = tmp;
+    std::memcpy(d->camera, h.camera, sizeof h.camera);
+    char* p = block + pad8(sizeof(rt_scene_desc));
+    const void* ptrs[17];
+    bool ok = true;
+    for (int i = 0; i < 17 && ok; i++) {
+        ptrs[i] = a[i].bytes ? p : nullptr;
+        const size_t n = pad8(a[i].bytes);
+        if (n) ok = std::fread(p, 1, n, f) == n;
+        p += n;
+    }
+    std::fclose(f);
+    if (!ok) { std::free(block); return fail(RT_EINVAL, std::string("short read from ") + path); }
+    d->node_bbox = (const double*) ptrs[0]; d->node_child = (const int32_t*) ptrs[1]; d->roots = (const int32_t*) ptrs[2];
+    d->prim_kind = (const int32_t*) ptrs[3]; d->prim_flags = (const int32_t*) ptrs[4]; d->prim_mat = (const int32_t*) ptrs[5]; d->prim_data = (const double*) ptrs[6];
+    d->mat_kind = (const int32_t*) ptrs[7]; d->mat_tex = (const int32_t*) ptrs[8]; d->mat_data = (const double*) ptrs[9];
+    d->tex_kind = (const int32_t*) ptrs[10]; d->tex_data = (const double*) ptrs[11]; d->tex_pixels = (const uint8_t*) ptrs[12];
+    d->light_kind = (const int32_t*) ptrs[13]; d->light_flags = (const int32_t*) ptrs[14]; d->light_mat = (const int32_t*) ptrs[15]; d->light_data = (const double*) ptrs[16];
+    const int rc = validate(d);                 // a cache is input like any other: index ranges are checked before anything walks it
+    if (rc) { std::free(block); return rc; }
+    *out = d;
+    return RT_OK;
+}
+
+int rt_scene_desc_free(rt_scene_desc* d) { std::free(d); return RT_OK; }
+
+int rt_checkpoint_save(const char* path, const void* accum_dev, int is_fp64, int32_t width, int32_t height, int32_t spp_done, uint64_t seed)
+{
+    if (!path || !accum_dev || width <= 0 || height <= 0 || spp_done < 0) return fail(RT_EINVAL, "path, accum_dev, a positive size and spp_done >= 0 are required");
+    const size_t bytes = (size_t) width * height * 3 * (is_fp64 ? 8 : 4);
+    std::vector<char> host(bytes);
+    HIP_TRY(hipMemcpy(host.data(), accum_dev, bytes, hipMemcpyDeviceToHost));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RT_EINVAL, std::string("cannot write ") + path);
+    CheckpointHeader h{};
+    std::memcpy(h.magic, "RTCKPT01", 8);
+    h.width = width; h.height = height; h.spp_done = spp_done; h.is_fp64 = is_fp64 ? 1 : 0; h.seed = seed;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(host.data(), 1, bytes, f) == bytes;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : fail(RT_EINVAL, std::string("short write to ") + path);
+}
+
+int rt_checkpoint_load(const char* path, void* accum_dev, int is_fp64, int32_t width, int32_t height, int32_t* spp_done, uint64_t* seed)
+{
+    if (!path || !accum_dev || !spp_done) return fail(RT_EINVAL, "path, accum_dev and spp_done are required");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(RT_EINVAL, std::string("cannot read ") + path);
+    CheckpointHeader h{};
+    const bool head = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "RTCKPT01", 8) == 0;
+    if (!head || h.width != width || h.height != height || h.is_fp64 != (is_fp64 ? 1 : 0) || h.spp_done < 0) {
+        std::fclose(f);
+        return fail(RT_EINVAL, std::string(path) + (head ? ": checkpoint of a different frame geometry or precision" : " is not a checkpoint"));
+    }
+    const size_t bytes = (size_t) width * height * 3 * (is_fp64 ? 8 : 4);
+    std::vector<char> host(bytes);
+    const bool ok = std::fread(host.data(), 1, bytes, f) == bytes;
+    std::fclose(f);
+    if (!ok) return fail(RT_EINVAL, std::string("short read from ") + path);
+    HIP_TRY(hipMemcpy(accum_dev, host.data(), bytes, hipMemcpyHostToDevice));
+    *spp_done = h.spp_done;
+    if (seed) *seed = h.seed;
+    return RT_OK;
+}
+
 int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host)
 {
     if (n <= 0 || !out_host) return fail(RT_EINVAL, "n > 0 and out_host are required");

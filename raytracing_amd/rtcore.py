@@ -15,7 +15,8 @@ FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 
 EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_fast", "rt_buffer_alloc", "rt_buffer_free",
-           "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version"]
+           "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
+           "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
 
 class RtError(RuntimeError):
@@ -72,6 +73,11 @@ def load_library():
         L.rt_buffer_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_buffer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_debug_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+        L.rt_scene_desc_save.argtypes = [C.POINTER(SceneDesc), C.c_char_p]
+        L.rt_scene_desc_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(SceneDesc))]
+        L.rt_scene_desc_free.argtypes = [C.POINTER(SceneDesc)]
+        L.rt_checkpoint_save.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
+        L.rt_checkpoint_load.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -192,6 +198,51 @@ class Scene:
         finally:
             acc.free()
             rgb.free()
+
+
+def desc_to_arrays(desc):
+    """SceneDesc (by value or pointer contents) -> dict of numpy copies, the inverse of make_desc (used by the cache round trip)."""
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+    d = desc
+    return dict(
+        node_bbox=arr(d.node_bbox, d.n_nodes * 6, np.float64).reshape(-1, 6), node_child=arr(d.node_child, d.n_nodes * 2, np.int32).reshape(-1, 2),
+        roots=arr(d.roots, d.n_roots, np.int32), prim_kind=arr(d.prim_kind, d.n_prims, np.int32), prim_flags=arr(d.prim_flags, d.n_prims, np.int32),
+        prim_mat=arr(d.prim_mat, d.n_prims, np.int32), prim_data=arr(d.prim_data, d.n_prims * PRIM_STRIDE, np.float64).reshape(-1, PRIM_STRIDE),
+        mat_kind=arr(d.mat_kind, d.n_mats, np.int32), mat_tex=arr(d.mat_tex, d.n_mats, np.int32),
+        mat_data=arr(d.mat_data, d.n_mats * MAT_STRIDE, np.float64).reshape(-1, MAT_STRIDE),
+        tex_kind=arr(d.tex_kind, d.n_tex, np.int32), tex_data=arr(d.tex_data, d.n_tex * TEX_STRIDE, np.float64).reshape(-1, TEX_STRIDE),
+        tex_pixels=arr(d.tex_pixels, d.n_pixel_bytes, np.uint8), n_pixel_bytes=int(d.n_pixel_bytes),
+        light_kind=arr(d.light_kind, d.n_lights, np.int32), light_flags=arr(d.light_flags, d.n_lights, np.int32),
+        light_mat=arr(d.light_mat, d.n_lights, np.int32), light_data=arr(d.light_data, d.n_lights * PRIM_STRIDE, np.float64).reshape(-1, PRIM_STRIDE),
+        camera=np.array(list(d.camera), np.float64))
+
+
+def save_scene_cache(desc_arrays, path):
+    """Flattened scene (dict as for Scene()) -> binary cache file (rt_scene_desc_save)."""
+    desc, keep = make_desc(desc_arrays)
+    _check(load_library().rt_scene_desc_save(C.byref(desc), os.fsencode(path)))
+
+
+def load_scene_cache(path):
+    """Binary cache file -> dict of arrays (rt_scene_desc_load + copy + rt_scene_desc_free)."""
+    L = load_library()
+    p = C.POINTER(SceneDesc)()
+    _check(L.rt_scene_desc_load(os.fsencode(path), C.byref(p)))
+    try:
+        return desc_to_arrays(p.contents)
+    finally:
+        L.rt_scene_desc_free(p)
+
+
+def checkpoint_save(path, accum_ptr, is_fp64, width, height, spp_done, seed):
+    _check(load_library().rt_checkpoint_save(os.fsencode(path), C.c_void_p(accum_ptr), int(is_fp64), width, height, spp_done, seed))
+
+
+def checkpoint_load(path, accum_ptr, is_fp64, width, height):
+    spp, seed = C.c_int32(), C.c_uint64()
+    _check(load_library().rt_checkpoint_load(os.fsencode(path), C.c_void_p(accum_ptr), int(is_fp64), width, height, C.byref(spp), C.byref(seed)))
+    return spp.value, seed.value
 
 
 def resolve(accum_ptr, is_fp64, n_pixels, spp, rgb_ptr, stream=None):

@@ -251,6 +251,43 @@ def test_empty_work_is_well_defined(R, golden_dir):
     osc.free()
 
 
+def test_scene_cache_and_checkpoint_resume(R, golden_dir, tmp_path):
+    """SURVEY 8f-3.  A scene loaded from the binary cache gives the original's first hits bit for bit; a frame rendered as
+    samples [0,5), checkpointed to disk, restored into a fresh buffer and continued with [5,12) + RT_FLAG_ACCUMULATE equals
+    the uninterrupted 12-sample frame bit for bit in fp64 mode (streams are keyed by the global sample index)."""
+    g, m = load(golden_dir, "mixed")
+    osc = SCENES["mixed"][1](golden_dir, m)
+    d = osc.export()
+    path = str(tmp_path / "scene.rtsc")
+    R.save_scene_cache(d, path)
+    sc0, sc1 = R.Scene(d), R.Scene(R.load_scene_cache(path))
+    rays = g["mixed_fh_rays"].reshape(-1, 7)
+    a, b = sc0.first_hit(rays), sc1.first_hit(rays)
+    for k in ("prim", "front", "nbox", "nleaf", "hash"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64))
+    w, h, depth = m["width"], m["height"], 12
+    whole, _, _ = sc1.render_to_host(w, h, 0, 12, depth, R.MODE_REFERENCE_FP64, seed=8)
+    acc = R.DeviceBuffer(w * h * 3 * 8)
+    sc1.render(acc.ptr, w, h, 0, 5, depth, R.MODE_REFERENCE_FP64, seed=8)
+    ck = str(tmp_path / "frame.rtck")
+    R.checkpoint_save(ck, acc.ptr, True, w, h, 5, 8)
+    acc.free()
+    acc2 = R.DeviceBuffer(w * h * 3 * 8)
+    done, seed = R.checkpoint_load(ck, acc2.ptr, True, w, h)
+    assert (done, seed) == (5, 8)
+    sc1.render(acc2.ptr, w, h, done, 12, depth, R.MODE_REFERENCE_FP64, seed=seed, flags=R.FLAG_ACCUMULATE)
+    resumed = acc2.download(np.float64, (h, w, 3))
+    assert np.array_equal(resumed.view(np.uint64), whole.view(np.uint64))
+    with pytest.raises(R.RtError):
+        R.checkpoint_load(ck, acc2.ptr, True, w + 1, h)          # another frame geometry
+    with pytest.raises(R.RtError):
+        R.checkpoint_load(ck, acc2.ptr, False, w, h)             # another precision
+    acc2.free()
+    sc0.destroy(); sc1.destroy()
+    osc.free()
+
+
 def test_resolve_matches_oracle(R):
     rng = np.random.default_rng(3)
     sums = np.concatenate([rng.uniform(0, 40, 3000), [0.0, 1e-9, 16.0, 15.999999, 1e9, 5e-324]]).reshape(-1, 3)
