@@ -678,20 +678,26 @@ template <typename R> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const 
 }
 
 // material::shading.  wo keeps its default (origin 0, direction 0, time 0: `ray wo;` raytracing.cpp:41) when the
-// material does not set it (phong's specular and diffuse branches).
-template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
-                                                         Ray<R>& wo, vec3<R>& att, bool& spec)
+// material does not set it (phong's specular and diffuse branches): `dir_set` stays false.
+// The per-material branches produce only the direction; the scattered ray is assembled once, after they have
+// rejoined (mat_shading below).  Assigning the whole ray inside every branch made the compiler's output fragile:
+// with some flag combinations lanes on the dielectric branch came out with o.z and time of the scattered ray holding
+// temporaries of the other branches (found by comparing per-pixel ray counts with the fp64 mode; guarded by
+// tests/test_gpu_parity.py::test_fast_ray_counts_match_fp64_per_pixel).
+template <typename R> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+                                                         vec3<R>& dir, bool& dir_set, vec3<R>& att, bool& spec)
 {
+    dir_set = true;
     switch (m.kind) {
     case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
         spec = false;
-        wo.o = h.pos; wo.from = h.id; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
+        dir = cosine_sample(g, h.normal);
         att = texc;
         return true;
     case RT_MAT_METAL: {                                                                    // material.hpp:74-82
         vec3<R> next = reflect(normalize(wi.d), h.normal);
         vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
-        wo.o = h.pos; wo.from = h.id; wo.d = next + fuzz; wo.time = wi.time;
+        dir = next + fuzz;
         att = texc;
         spec = true;
         return true;
@@ -699,7 +705,7 @@ template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m
     case RT_MAT_DIELECTRIC:                                                                 // material.hpp:105-125
         spec = true;
         att = vec3<R>(R(1), R(1), R(1));
-        wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
+        dir = glass_dir(g, wi, h, m.d[0]);
         return true;
     case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
@@ -707,20 +713,32 @@ template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m
         if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
             att = vec3<R>(m.d[4], m.d[5], m.d[6]);
             spec = true;
+            dir_set = false;
             return true;
         }
         if (nz3(m.d + 10)) {
             spec = true;
             att = vec3<R>(m.d[10], m.d[11], m.d[12]);
-            wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
+            dir = glass_dir(g, wi, h, m.d[14]);
             return true;
         }
         spec = false;
         att = base;
+        dir_set = false;
         return true;
     }
     default: return false;                                                                  // emissive material.hpp:156-159
     }
+}
+
+template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+                                                         Ray<R>& wo, vec3<R>& att, bool& spec)
+{
+    vec3<R> dir;
+    bool dir_set = false;
+    if (!mat_scatter(g, m, wi, h, texc, dir, dir_set, att, spec)) return false;
+    if (dir_set) { wo.o = h.pos; wo.from = h.id; wo.d = dir; wo.time = wi.time; }
+    return true;
 }
 
 template <typename R> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)

@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
     vec3<float> beta, L;
     Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f;
 
+    unsigned long long census[3] = { 0, 0, 0 };
     unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // diagnostic: wave time per phase (regenerate, nodes, leaves, shade)
     auto lap = [&](int phase) { if (kCount) { const unsigned long long t1 = wall_clock64(); cyc[phase] += t1 - t0; t0 = t1; } };
 
@@ -165,6 +166,12 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
             for (;;) {
                 const int n_inner = __popcll(__ballot(tv.cur >= 0));
                 if (n_inner == 0 || n_inner * 256 < n_trav * node_keep) break;
+                if (kCount) {   // census of the lanes that sit this node step out: on a leaf / hit known / no path
+                    const unsigned c0 = (unsigned) __popcll(__ballot(tv.cur < 0 && tv.cur != RT_BVH_SENTINEL));
+                    const unsigned c1 = (unsigned) __popcll(__ballot(alive && tv.cur == RT_BVH_SENTINEL));
+                    const unsigned c2 = (unsigned) __popcll(__ballot(!alive));
+                    census[0] += c0; census[1] += c1; census[2] += c2;
+                }
                 if (tv.cur >= 0) {
                     float tl, tr; bool hl, hr;
                     int32_t c_left, c_right;
@@ -292,6 +299,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
         if (lane == 0) {
             atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb);
             for (int k = 0; k < 4; k++) atomicAdd(&counters[8 + k], cyc[k]);
+            for (int k = 0; k < 3; k++) atomicAdd(&counters[12 + k], census[k]);
         }
     }
 }

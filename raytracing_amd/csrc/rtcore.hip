@@ -535,6 +535,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         unsigned long long c[16];
         HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
         for (int k = 0; k < 4; k++) stats->phase_ticks[k] = c[8 + k];
+        if (getenv("RT_DEBUG") && c[4]) fprintf(stderr, "[rtcore] node-step census per wave step: inner %.2f leaf %.2f hit-known %.2f no-path %.2f\n", (double) c[2] / 2 / c[4], (double) c[12] / c[4], (double) c[13] / c[4], (double) c[14] / c[4]);
         stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
     }
     return RT_OK;

@@ -175,6 +175,29 @@ def test_host_built_scenes_fp64_and_fp32_vs_oracle(R, which, depth):
     hs.free()
 
 
+@pytest.mark.parametrize("which,limit", [("random_spheres", 0.004), ("deep_bounce", 0.010), ("cornell", 0.010)])
+def test_fast_ray_counts_match_fp64_per_pixel(R, which, limit):
+    """Per-pixel ray counts (RT_FLAG_DEBUG_RAY_COUNTS) of every fp32 kernel variant against the fp64 reference mode on the same
+    streams, WITHOUT early exit, so the segments after a specular bounce (rejected by the reference's pdf-0 rule, but still
+    traced by it) are covered too.  One wrong ray anywhere changes the number of segments that follow, so this catches what the
+    RMSE bars cannot: it is how the scattered-ray corruption described at mat_scatter() (rt_device.h) was found -- 2.7 % / 11 %
+    of the pixels differed then, against 0.1 % / 0.3 % of fp32-vs-fp64 silhouette grazes now.  Bars: differing pixels <= 0.4 %
+    (spheres) / 1 % (deep-bounce glass and mirrors, cornell), total rays within 0.05 %."""
+    from raytracing_amd.host_scenes import HostScene
+    w, h, spp, depth = 192, 108, 8, 50
+    hs = HostScene.cornell(w, h) if which == "cornell" else getattr(HostScene, which)(w, h, 1)
+    sc = hs.upload()
+    ref, _, st64 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_REFERENCE_FP64, seed=3, flags=R.FLAG_DEBUG_RAY_COUNTS)
+    for name, mode, flags in (("fast", R.MODE_FAST_FP32, 0), ("fast_lanesync", R.MODE_FAST_FP32, R.FLAG_LEGACY_LOOP),
+                              ("reftree", R.MODE_FP32_REFERENCE_TREE, 0), ("fast_wavefront", R.MODE_FAST_FP32, R.FLAG_WAVEFRONT)):
+        cnt, _, st = sc.render_to_host(w, h, 0, spp, depth, mode, seed=3, flags=flags | R.FLAG_DEBUG_RAY_COUNTS)
+        frac = float((cnt[..., 0].astype(np.float64) != ref[..., 0]).mean())
+        assert frac <= limit, (name, frac)
+        assert abs(st["rays"] - st64["rays"]) <= 5e-4 * st64["rays"], (name, st["rays"], st64["rays"])
+    sc.destroy()
+    hs.free()
+
+
 def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     """RT_QNODES=1: the fast mode walks the 32-byte quantised twin of its tree (two vector loads per node instead of four).
     Decoded boxes contain the real ones, so closest hits -- and with the same RNG streams the frame -- do not change, except

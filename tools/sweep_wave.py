@@ -42,7 +42,8 @@ for tk, nk, rm in itertools.product(ints(args.trav), ints(args.node), ints(args.
             os.environ[name] = str(v)
     sc = hs.upload()
     sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags)
-    t = min(sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags)["kernel_ms"] for _ in range(2))
+    runs = [sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags) for _ in range(2)]
+    t = min(r["kernel_ms"] for r in runs)
     msg = f"{args.which} trav_keep {tk} node_keep {nk} regen_min {rm}: {t:.2f} ms"
     if args.count:
         st = sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=R.FLAG_COUNT_TESTS | args.flags)
