@@ -132,8 +132,13 @@ def main():
         "obj": (["obj", obj, 5, 64, 48, 8, 12], dict(seed=5, width=64, height=48, spp=8, depth=12)),
         # the reference's own main() scene (raytracing.cpp:77-90: Cornell box, depth 10) at a small size
         "cornell": (["cornell", 1, 56, 56, 16, 10], dict(seed=1, width=56, height=56, spp=16, depth=10)),
+        # volume / fog: sphere-bounded media of all_feature_test() (demo.hpp:117-134) over a ground rect
+        "smoke": (["smoke", 2, 64, 48, 16, 12], dict(seed=2, width=64, height=48, spp=16, depth=12)),
     }
+    only = sys.argv[1:]          # optional: names of the fixtures to (re)generate
     for name, (args, meta) in jobs.items():
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as tmp:
             arrays, info = run(args, tmp)
         for k, v in meta.items():

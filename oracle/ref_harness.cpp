@@ -70,7 +70,7 @@ static double sm_unit() { return (sm_next() >> 11) * (1.0 / 9007199254740992.0);
 static double sm_range(double a, double b) { return a + (b - a) * sm_unit(); }
 
 // ---------------------------------------------------------------- tree dump
-enum { K_NODE = 0, K_SPHERE = 1, K_MSPHERE = 2, K_PLANEXY = 3, K_PLANEXZ = 4, K_PLANEYZ = 5, K_TRIANGLE = 6, K_BOX = 7 };
+enum { K_NODE = 0, K_SPHERE = 1, K_MSPHERE = 2, K_PLANEXY = 3, K_PLANEXZ = 4, K_PLANEYZ = 5, K_TRIANGLE = 6, K_BOX = 7, K_VOLUME = 8 };
 enum { ROW = 56 };   // doubles per pre-order entry
 
 struct pentry {
@@ -132,6 +132,7 @@ struct tree_dump {
         else if (const metal* l = dynamic_cast<const metal*>(m)) { row[0] = 2; row[1] = l->roughness; put_tex(l->base_color, row + 2); }
         else if (const dielectric* l = dynamic_cast<const dielectric*>(m)) { row[0] = 3; row[1] = l->ior; }
         else if (const emissive* l = dynamic_cast<const emissive*>(m)) { row[0] = 4; put_tex(l->emission, row + 2); }
+        else if (const fog* l = dynamic_cast<const fog*>(m)) { row[0] = 6; put_tex(l->base_color, row + 2); }
         else if (const phong* p = dynamic_cast<const phong*>(m)) {
             row[0] = 5;
             if (p->diffuse_map) put_tex(p->diffuse_map, row + 2);
@@ -182,6 +183,12 @@ struct tree_dump {
                 aabb bb; e.o->bounding_box(0, 0, bb);          // the wrapped object's box, as the bvh builder sees it
                 for (int k = 0; k < 3; k++) { g[11 + k] = bb.min()[k]; g[14 + k] = bb.max()[k]; }
                 mat = dynamic_cast<const planexy*>(bx->xy0)->mat;
+            } else if (const volume* vo = dynamic_cast<const volume*>(e.base)) {
+                // volume (primitive.hpp:329-396) around a sphere boundary: one leaf; the boundary's own material is not used
+                const sphere* sb = dynamic_cast<const sphere*>(vo->surface);
+                r[0] = K_VOLUME;
+                if (sb) { for (int k = 0; k < 3; k++) g[k] = sb->center[k]; g[3] = sb->radius; }
+                g[4] = vo->neg_inv_d; mat = vo->mat;
             } else {
                 r[0] = -1;
             }
@@ -290,6 +297,35 @@ static built_scene* build_cornell(int w, int h)
     return b;
 }
 
+// volume / fog (primitive.hpp:329-396, material.hpp:165-181): the sphere-bounded media of all_feature_test() (demo.hpp:117-134:
+// global haze in a radius-5000 sphere, a glass ball filled with blue fog, moving / glass / fuzzy-metal / mirror spheres) over a ground
+// rect, plus a free-standing smoke ball; the light is flipped so that it shines downwards (the demo's is not, and lights nothing)
+static built_scene* build_smoke(int w, int h)
+{
+    built_scene* b = new built_scene();
+    b->scn = new scene(w, h);
+    group grp;
+    grp.add(new planexz(-1000, 1000, -1000, 1000, 0, new lambertian(vec3d(0.48, 0.83, 0.53))));
+    grp.add(new flip(new planexz(123, 423, 147, 412, 554, new emissive(vec3d(7, 7, 7)))));
+    grp.add(new msphere(vec3d(400, 400, 200), vec3d(430, 400, 200), 0, 1, 50, new lambertian(vec3d(0.7, 0.3, 0.1))));
+    grp.add(new sphere(vec3d(260, 150, 45), 50, new dielectric(1.5)));
+    grp.add(new sphere(vec3d(0, 150, 145), 50, new metal(vec3d(0.8, 0.8, 0.9), 1)));
+    grp.add(new volume(new sphere(vec3d(0, 0, 0), 5000, new dielectric(1.5)), 0.0002, vec3d(1, 1, 1)));
+    object* ball = new sphere(vec3d(360, 150, 145), 70, new dielectric(1.5));
+    grp.add(ball);
+    grp.add(new volume(ball, 0.2, vec3d(0.2, 0.4, 0.9)));
+    grp.add(new sphere(vec3d(400, 200, 400), 100, new lambertian(new checker(vec3d(0.2, 0.3, 0.1), vec3d(0.9, 0.9, 0.9)))));
+    grp.add(new sphere(vec3d(220, 280, 300), 50, new metal(vec3d(1, 1, 1), 0)));
+    grp.add(new volume(new sphere(vec3d(150, 100, 250), 80, new dielectric(1.5)), 0.01, vec3d(0.9, 0.9, 0.9)));
+    b->scn->add_object(grp);
+    b->scn->add_light(new flip(new planexz(123, 423, 147, 412, 554, new emissive(vec3d(7, 7, 7)))));
+    b->scn->set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(w) / h, 0, 10, 0, 1));
+    b->scn->build_bvh();
+    b->root = b->scn->objects.content()[0];
+    b->td.walk(b->root);
+    return b;
+}
+
 // OBJ scene through the reference loader (loader.hpp:20-38)
 static built_scene* build_obj(const char* path, int w, int h)
 {
@@ -328,7 +364,7 @@ static void dump_lights(const char* name, const scene& scn)
 }
 
 // ---------------------------------------------------------------- first-hit fixture
-static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_side, int n_random, double lo[3], double hi[3])
+static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_side, int n_random, double lo[3], double hi[3], bool cross_check = true)
 {
     std::vector<ray> rays;
     // (a) primary rays through the reference camera (lens + shutter randoms come from rand())
@@ -373,9 +409,12 @@ static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_si
         intersection x; x.t = 0; x.frontward = false;
         bool h = rewalk(b->td, 0, r, x, st);
         // cross-check against the reference's own entry point (group.hpp:68-83 -> bvh.hpp:58-68)
-        intersection y; y.t = 0;
-        bool h2 = b->scn->objects.intersect(r, y);
-        if (h != h2 || (h && (memcmp(&x.t, &y.t, 8) != 0 || x.mat != y.mat))) mism++;
+        // (not for scenes with volumes: volume::intersect draws from rand(), so a second walk sees other free-flight distances)
+        if (cross_check) {
+            intersection y; y.t = 0;
+            bool h2 = b->scn->objects.intersect(r, y);
+            if (h != h2 || (h && (memcmp(&x.t, &y.t, 8) != 0 || x.mat != y.mat))) mism++;
+        }
         hit[i] = h ? b->td.first.at(b->td.pre[st.hit_entry].o) : -1;
         tout[i] = h ? x.t : 0.0;
         nbox[i] = st.nbox; nleaf[i] = st.nleaf; hash[i] = st.hash;
@@ -621,6 +660,17 @@ int main(int argc, char** argv)
         double lo[3] = { 1, 1, 1 }, hi[3] = { 554, 554, 554 };
         do_firsthit("cornell", b, 48, 1600, lo, hi);
         do_image("cornell", b, w, h, spp, depth);
+    }
+    else if (mode == "smoke") {         // smoke <seed> <w> <h> <spp> <depth>
+        unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+        srand(seed);
+        built_scene* b = build_smoke(w, h);
+        dump_f64("smoke_tree", b->td.rows());
+        dump_lights("smoke_lights", *b->scn);
+        dump_camera("smoke_camera", b->scn->render_camera);
+        double lo[3] = { -100, 1, -100 }, hi[3] = { 554, 554, 554 };
+        do_firsthit("smoke", b, 32, 1024, lo, hi, false);      // volume::intersect draws from rand() during these walks too
+        do_image("smoke", b, w, h, spp, depth);
     }
     else if (mode == "time_c0") {       // time_c0 <seed> <w> <h> <spp> <depth> : throughput of the real reference, 1 thread
         unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);

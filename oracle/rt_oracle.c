@@ -320,6 +320,11 @@ static int mat_shading(const orc_scene* s, orc_rng* g, const orc_mat* m, const r
         return 1;
     case ORC_MAT_EMISSIVE:                                               /* material.hpp:156-159 */
         return 0;
+    case ORC_MAT_FOG:                                                    /* material.hpp:174-180; pdf() is the base class's 0 (:14) */
+        *spec = 0;
+        *wo = mkray(x->pos, rnd_sphere(g), wi->time, wi->t_min, wi->t_max);
+        *att = tex_color(s, m->tex, x->pos, x->uv);
+        return 1;
     case ORC_MAT_PHONG: {                                                /* material.hpp:211-255 */
         if (nz3(m->d + 7)) return 0;
         v3 base = (m->tex >= 0) ? tex_color(s, m->tex, x->pos, x->uv) : V(m->d[1], m->d[2], m->d[3]);
@@ -508,19 +513,47 @@ static int box_hit(const orc_obj* o, const ray* r, isect* x)
     return 1;
 }
 
-static int obj_hit(const orc_obj* o, const ray* r, isect* x);
+static int obj_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g);
 
-static int bvh_hit(const orc_obj* o, const ray* r, isect* x)            /* bvh.hpp:58-68 */
+static int bvh_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g) /* bvh.hpp:58-68 */
 {
     if (!aabb_hit(&o->box, r)) return 0;
-    int hl = obj_hit(o->l, r, x);
+    int hl = obj_hit(o->l, r, x, g);
     double tmr = hl ? x->t : r->t_max;
     ray rr = mkray(r->o, r->d, r->time, r->t_min, tmr);
-    int hr = obj_hit(o->r, &rr, x);
+    int hr = obj_hit(o->r, &rr, x, g);
     return hl || hr;
 }
 
-static int obj_hit(const orc_obj* o, const ray* r, isect* x)
+/* volume (primitive.hpp:329-396): constant-density medium inside `surface` (o->l).  The free-flight distance is drawn
+ * INSIDE intersect (:373), so the stream position depends on which volumes a traversal reaches and in what order.
+ * g == NULL (the instrumented first-hit walk, which has no stream): a volume is never hit. */
+static int volume_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g)
+{
+    isect c1, c2; memset(&c1, 0, sizeof c1); memset(&c2, 0, sizeof c2);
+    if (!g) return 0;
+    ray all = mkray(r->o, r->d, r->time, -ORC_INF, ORC_INF);
+    if (!obj_hit(o->l, &all, &c1, g)) return 0;                          /* :349 */
+    ray rest = mkray(r->o, r->d, r->time, c1.t + 0.0001, ORC_INF);
+    if (!obj_hit(o->l, &rest, &c2, g)) return 0;                         /* :353 */
+    if (c1.t < r->t_min) c1.t = r->t_min;
+    if (c2.t > r->t_max) c2.t = r->t_max;
+    if (c1.t >= c2.t) return 0;
+    if (c1.t < 0) c1.t = 0;
+    double ray_length = vlen(r->d);
+    double inner_length = (c2.t - c1.t) * ray_length;
+    double intersect_distance = o->g[4] * log(rnd(g));                  /* :373, g[4] = neg_inv_d */
+    if (intersect_distance > inner_length) return 0;
+    x->t = c1.t + intersect_distance / ray_length;
+    x->pos = ray_at(r, x->t);
+    x->normal = V(1, 0, 0);
+    x->front = 0;
+    x->mat = o->mat;
+    x->leaf = o;                                                        /* uv_coord keeps whatever the record held (:379-383) */
+    return 1;
+}
+
+static int obj_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g)
 {
     switch (o->kind) {
     case ORC_SPHERE: return sphere_hit(o, V(o->g[0], o->g[1], o->g[2]), o->g[3], r, x);
@@ -528,24 +561,25 @@ static int obj_hit(const orc_obj* o, const ray* r, isect* x)
     case ORC_PLANEXY: case ORC_PLANEXZ: case ORC_PLANEYZ: return plane_hit(o, r, x);
     case ORC_TRIANGLE: return tri_hit(o, r, x);
     case ORC_BOX: return box_hit(o, r, x);
+    case ORC_VOLUME: return volume_hit(o, r, x, g);
     case O_FLIP:                                                        /* transform.hpp:129-136 */
-        if (!obj_hit(o->l, r, x)) return 0;
+        if (!obj_hit(o->l, r, x, g)) return 0;
         x->front = !x->front;
         x->leaf = o;
         return 1;
-    case O_BVH: return bvh_hit(o, r, x);
+    case O_BVH: return bvh_hit(o, r, x, g);
     }
     return 0;
 }
 
-static int group_hit(orc_obj* const* objs, int n, const ray* r, isect* x)   /* group.hpp:68-83 */
+static int group_hit(orc_obj* const* objs, int n, const ray* r, isect* x, orc_rng* g)   /* group.hpp:68-83 */
 {
     isect tmp; memset(&tmp, 0, sizeof tmp);
     int has = 0;
     double closest = r->t_max;
     for (int i = 0; i < n; i++) {
         ray rr = mkray(r->o, r->d, r->time, r->t_min, closest);
-        if (obj_hit(objs[i], &rr, &tmp)) { has = 1; closest = tmp.t; *x = tmp; }
+        if (obj_hit(objs[i], &rr, &tmp, g)) { has = 1; closest = tmp.t; *x = tmp; }
     }
     return has;
 }
@@ -597,6 +631,7 @@ static int obj_bbox(const orc_obj* o, double start, double end, aabb* out)
         *out = b;
         return 1;
     }
+    case ORC_VOLUME: return obj_bbox(o->l, start, end, out);            /* primitive.hpp:387-390 */
     case O_FLIP: return obj_bbox(o->l, start, end, out);                /* transform.hpp:138-141 */
     case O_BVH: *out = o->box; return 1;                                /* bvh.hpp:70-74 */
     }
@@ -804,6 +839,7 @@ int orc_mat_lambertian(orc_scene* s, int tex) { orc_mat m; memset(&m, 0, sizeof 
 int orc_mat_metal(orc_scene* s, int tex, double roughness)
 { orc_mat m; memset(&m, 0, sizeof m); m.kind = ORC_MAT_METAL; m.tex = tex; m.d[0] = roughness < 1 ? roughness : 1; return add_mat(s, m); } /* material.hpp:65 */
 int orc_mat_dielectric(orc_scene* s, double ior) { orc_mat m; memset(&m, 0, sizeof m); m.kind = ORC_MAT_DIELECTRIC; m.tex = -1; m.d[0] = ior; return add_mat(s, m); }
+int orc_mat_fog(orc_scene* s, int tex) { orc_mat m; memset(&m, 0, sizeof m); m.kind = ORC_MAT_FOG; m.tex = tex; return add_mat(s, m); }
 int orc_mat_emissive(orc_scene* s, int tex) { orc_mat m; memset(&m, 0, sizeof m); m.kind = ORC_MAT_EMISSIVE; m.tex = tex; return add_mat(s, m); }
 int orc_mat_phong(orc_scene* s, const double* k, double ns, double ni, int diffuse_tex)
 {
@@ -847,6 +883,16 @@ int orc_add_box(orc_scene* s, const double mn[3], const double mx[3], int wrappe
     return finish_add(s, o, flip, to_lights);
 }
 
+/* volume(new sphere(center, radius, <any material>), density, fog): the boundary's own material is never used */
+int orc_add_volume(orc_scene* s, const double c[3], double radius, double density, int fog_mat, int to_lights)
+{
+    orc_obj* b = new_obj(ORC_SPHERE); b->g[0] = c[0]; b->g[1] = c[1]; b->g[2] = c[2]; b->g[3] = radius;
+    orc_obj* o = new_obj(ORC_VOLUME); o->mat = fog_mat; o->l = b;
+    for (int k = 0; k < 4; k++) o->g[k] = b->g[k];
+    o->g[4] = -1.0 / density;                                           /* primitive.hpp:336 */
+    return finish_add(s, o, 0, to_lights);
+}
+
 static orc_obj* mk_triangle(const double p[9], const double n[9], const double uv[6], int mat)   /* polygon.hpp:26-38 */
 {
     orc_obj* o = new_obj(ORC_TRIANGLE); o->mat = mat;
@@ -882,6 +928,7 @@ void orc_add_prims_bulk(orc_scene* s, int n, const int32_t* kind, const int32_t*
         case ORC_SPHERE: orc_add_sphere(s, g, g[3], mat[i], fl, to_lights); break;
         case ORC_MSPHERE: orc_add_msphere(s, g, g + 3, g[6], g[7], g[8], mat[i], fl, to_lights); break;
         case ORC_BOX: orc_add_box(s, g, g + 3, flags[i] & 6, g[6], g[7], g + 8, mat[i], fl, to_lights); break;
+        case ORC_VOLUME: { int id = orc_add_volume(s, g, g[3], 1.0, mat[i], to_lights); orc_obj* o = to_lights ? s->lights[id] : s->prims[id]; o->g[4] = g[4]; break; }
         case ORC_TRIANGLE: {
             double p[9];
             for (int k = 0; k < 3; k++) { p[k] = g[k]; p[3 + k] = g[k] + g[3 + k]; p[6 + k] = g[k] + g[6 + k]; }
@@ -1051,6 +1098,31 @@ orc_scene* orc_build_cornell(int width, int height, unsigned seed)
     return s;
 }
 
+/* same scene as ref_harness.cpp build_smoke: sphere-bounded media (primitive.hpp:329-396) with fog (material.hpp:165-181) */
+orc_scene* orc_build_smoke(int width, int height, unsigned seed)
+{
+    orc_scene* s = orc_scene_new(width, height, seed);
+    orc_add_plane(s, ORC_PLANEXZ, -1000, 1000, -1000, 1000, 0, orc_mat_lambertian(s, orc_tex_constant(s, 0.48, 0.83, 0.53)), 0, 0);
+    orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 1, 0);
+    double m0[3] = { 400, 400, 200 }, m1[3] = { 430, 400, 200 }, c1[3] = { 260, 150, 45 }, c2[3] = { 0, 150, 145 }, zero[3] = { 0, 0, 0 };
+    double c3[3] = { 360, 150, 145 }, c4[3] = { 400, 200, 400 }, c5[3] = { 220, 280, 300 }, c6[3] = { 150, 100, 250 };
+    orc_add_msphere(s, m0, m1, 0, 1, 50, orc_mat_lambertian(s, orc_tex_constant(s, 0.7, 0.3, 0.1)), 0, 0);
+    orc_add_sphere(s, c1, 50, orc_mat_dielectric(s, 1.5), 0, 0);
+    orc_add_sphere(s, c2, 50, orc_mat_metal(s, orc_tex_constant(s, 0.8, 0.8, 0.9), 1), 0, 0);
+    orc_add_volume(s, zero, 5000, 0.0002, orc_mat_fog(s, orc_tex_constant(s, 1, 1, 1)), 0);
+    orc_add_sphere(s, c3, 70, orc_mat_dielectric(s, 1.5), 0, 0);
+    orc_add_volume(s, c3, 70, 0.2, orc_mat_fog(s, orc_tex_constant(s, 0.2, 0.4, 0.9)), 0);
+    int chk = orc_tex_checker(s, orc_tex_constant(s, 0.2, 0.3, 0.1), orc_tex_constant(s, 0.9, 0.9, 0.9));
+    orc_add_sphere(s, c4, 100, orc_mat_lambertian(s, chk), 0, 0);
+    orc_add_sphere(s, c5, 50, orc_mat_metal(s, orc_tex_constant(s, 1, 1, 1), 0), 0, 0);
+    orc_add_volume(s, c6, 80, 0.01, orc_mat_fog(s, orc_tex_constant(s, 0.9, 0.9, 0.9)), 0);
+    orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 1, 1);
+    double pos[3] = { 478, 278, -600 }, at[3] = { 278, 278, 0 }, up[3] = { 0, 1, 0 };
+    orc_set_camera(s, pos, at, up, 40, 0, 10, 0, 1);
+    orc_build_bvh(s);
+    return s;
+}
+
 /* ------------------------------------------------------------------ pre-order view */
 static int pre_walk(orc_scene* s, const orc_obj* o, int* cap)
 {
@@ -1103,7 +1175,7 @@ static void put_mat_row(const orc_scene* s, int mi, double* row)
     const orc_mat* m = &s->mats[mi];
     row[0] = m->kind;
     if (m->kind == ORC_MAT_METAL || m->kind == ORC_MAT_DIELECTRIC) row[1] = m->d[0];
-    if (m->kind != ORC_MAT_DIELECTRIC && m->tex >= 0) put_tex_row(s, m->tex, row + 2);
+    if (m->kind != ORC_MAT_DIELECTRIC && m->tex >= 0) put_tex_row(s, m->tex, row + 2);   /* fog: base_color, like lambertian */
     if (m->kind == ORC_MAT_PHONG) { for (int i = 0; i < 12; i++) row[9 + i] = m->d[1 + i]; row[21] = m->d[13]; row[22] = m->d[14]; }
 }
 static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int left, int right)
@@ -1120,7 +1192,7 @@ static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int lef
         return;
     }
     r[0] = base->kind;
-    int ng = base->kind == ORC_SPHERE ? 4 : base->kind == ORC_MSPHERE ? 9 : base->kind == ORC_TRIANGLE ? 24 : base->kind == ORC_BOX ? 11 : 5;
+    int ng = base->kind == ORC_SPHERE ? 4 : base->kind == ORC_VOLUME ? 5 : base->kind == ORC_MSPHERE ? 9 : base->kind == ORC_TRIANGLE ? 24 : base->kind == ORC_BOX ? 11 : 5;
     for (int k = 0; k < ng; k++) g[k] = base->g[k];
     if (base->kind == ORC_BOX) {                                        /* ref_harness.cpp tree_dump::rows, K_BOX */
         aabb bb; obj_bbox(o, 0, 0, &bb);
@@ -1215,21 +1287,21 @@ void orc_export(const orc_scene* s, double* node_bbox, int32_t* node_child, int3
 typedef struct { uint32_t nbox, nleaf; uint64_t hash; int hit_entry; } walk_stats;
 static inline void fnv(uint64_t* h, uint32_t v) { *h = (*h ^ (uint64_t) v) * 0x100000001B3ULL; }
 
-static int rewalk(const orc_scene* s, int idx, const ray* r, isect* x, walk_stats* st)
+static int rewalk(const orc_scene* s, int idx, const ray* r, isect* x, walk_stats* st, orc_rng* g)
 {
     const orc_obj* o = s->pre[idx];
     fnv(&st->hash, (uint32_t) idx);
     if (o->kind == O_BVH) {
         st->nbox++;
         if (!aabb_hit(&o->box, r)) return 0;
-        int hl = rewalk(s, s->pre_left[idx], r, x, st);
+        int hl = rewalk(s, s->pre_left[idx], r, x, st, g);
         double tmr = hl ? x->t : r->t_max;
         ray rr = mkray(r->o, r->d, r->time, r->t_min, tmr);
-        int hr = rewalk(s, s->pre_right[idx], &rr, x, st);
+        int hr = rewalk(s, s->pre_right[idx], &rr, x, st, g);
         return hl || hr;
     }
     st->nleaf++;
-    int hit = obj_hit(o, r, x);
+    int hit = obj_hit(o, r, x, g);
     if (hit) st->hit_entry = idx;
     return hit;
 }
@@ -1248,7 +1320,7 @@ void orc_first_hit(const orc_scene* s, int n, const double* rays, int32_t* entry
         for (int k = 0; k < s->n_objects; k++) {
             ray rr = mkray(r.o, r.d, r.time, r.t_min, closest);
             int he = st.hit_entry;
-            if (rewalk(s, s->root_entry[k], &rr, &tmp, &st)) { has = 1; closest = tmp.t; x = tmp; } else st.hit_entry = he;
+            if (rewalk(s, s->root_entry[k], &rr, &tmp, &st, (orc_rng*) &s->rng)) {   /* volumes draw from the scene's stream, like the harness' walk */ has = 1; closest = tmp.t; x = tmp; } else st.hit_entry = he;
         }
         entry_first[i] = has ? s->pre_first[st.hit_entry] : -1;
         prim_id[i] = has ? s->pre[st.hit_entry]->id : -1;
@@ -1272,7 +1344,7 @@ static v3 trace(orc_scene* s, orc_rng* g, const ray* wi, int depth, uint64_t* ra
     if (g_path_out && g_path_n < g_path_cap) { double* w = g_path_out + 7 * g_path_n++; w[0] = wi->o.x; w[1] = wi->o.y; w[2] = wi->o.z; w[3] = wi->d.x; w[4] = wi->d.y; w[5] = wi->d.z; w[6] = wi->time; }
     isect x; memset(&x, 0, sizeof x);
     (*rays)++;
-    if (!group_hit(s->objects, s->n_objects, wi, &x)) return V(0, 0, 0);
+    if (!group_hit(s->objects, s->n_objects, wi, &x, g)) return V(0, 0, 0);
 
     ray wo = ray_default();
     v3 att = V(0, 0, 0);
@@ -1440,7 +1512,7 @@ void orc_unit_prim(int n, const double* in, double* out, double* pdfs)
         ray r = mkray(o, d, q[6], q[7], q[8]);
         for (int k = 0; k < 5; k++) {
             isect x; memset(&x, 0, sizeof x);
-            int h = obj_hit(s->prims[k], &r, &x);
+            int h = obj_hit(s->prims[k], &r, &x, NULL);
             double* w = out + ((size_t) k * n + i) * 12;
             memset(w, 0, sizeof(double) * 12);
             w[0] = h;

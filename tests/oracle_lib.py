@@ -34,7 +34,8 @@ def lib():
         L.orc_build_c0.restype = C.c_void_p
         L.orc_build_mixed.restype = C.c_void_p
         L.orc_build_cornell.restype = C.c_void_p
-        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell"):
+        L.orc_build_smoke.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         _lib = L
     return _lib
@@ -63,6 +64,11 @@ class Scene:
     @classmethod
     def mixed(cls, width, height, seed=1):
         return cls(lib().orc_build_mixed(width, height, seed), width, height)
+
+    @classmethod
+    def smoke(cls, width, height, seed=1):
+        """sphere-bounded media (volume / fog) of all_feature_test() over a ground rect: ref_harness.cpp build_smoke"""
+        return cls(lib().orc_build_smoke(width, height, seed), width, height)
 
     @classmethod
     def cornell(cls, width, height, seed=1):
@@ -97,6 +103,9 @@ class Scene:
 
     def mat_emissive(self, tex):
         return lib().orc_mat_emissive(self.h, tex)
+
+    def mat_fog(self, tex):
+        return lib().orc_mat_fog(self.h, tex)
 
     def mat_phong(self, kd, ks, ke, tr, ns, ni, tex=-1):
         k = (C.c_double * 12)(*[float(x) for x in list(kd) + list(ks) + list(ke) + list(tr)])
@@ -398,6 +407,8 @@ def scene_from_arrays(d, seed=1):
             s.mat_dielectric(m[0])
         elif k == 4:
             s.mat_emissive(t)
+        elif k == 6:
+            s.mat_fog(t)
         else:
             s.mat_phong(m[1:4], m[4:7], m[7:10], m[10:13], m[13], m[14], t)
     I, D = C.c_int32, C.c_double

@@ -33,6 +33,7 @@ SCENES = {
     "c0_seed7": ("c0", 48, lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "mixed": ("mixed", 32, lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
     "cornell": ("cornell", 48, lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
+    "smoke": ("smoke", 32, lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "obj": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 
@@ -54,7 +55,10 @@ def test_scene_bvh_firsthit_image(golden_dir, name):
     assert_bits(s.tree_rows(), g[tag + "_tree"], "tree")
     assert_bits(s.light_rows(), g[tag + "_lights"], "lights")
     assert_bits(s.camera_fields(), g[tag + "_camera"], "camera")
-    # closest hit + traversal order (group.hpp:68-83, bvh.hpp:58-68, aabb.hpp:23-41, leaf intersects)
+    # camera::emit (camera.hpp:62-68): also keeps the rand() stream in step with the harness, which emits these rays first
+    assert_bits(s.primary_rays(side), g[tag + "_fh_rays"].reshape(-1, 7)[:side * side], "primary rays")
+    # closest hit + traversal order (group.hpp:68-83, bvh.hpp:58-68, aabb.hpp:23-41, leaf intersects); a volume on the way draws
+    # its free-flight distance from rand() inside intersect (primitive.hpp:373), in the harness' walk and here alike
     fh = s.first_hit(g[tag + "_fh_rays"])
     for k in ("entry", "nbox", "nleaf", "front", "hash"):
         assert np.array_equal(fh[k], g[f"{tag}_fh_{k}"]), k
@@ -64,8 +68,6 @@ def test_scene_bvh_firsthit_image(golden_dir, name):
     ids = s.entry_prim_ids()
     hit = fh["entry"] >= 0
     assert np.array_equal(ids[fh["entry"][hit]], fh["prim"][hit])
-    # camera::emit (camera.hpp:62-68): also keeps the rand() stream in step with the harness
-    assert_bits(s.primary_rays(side), g[tag + "_fh_rays"].reshape(-1, 7)[:side * side], "primary rays")
     # full render: trace (raytracing.cpp:30-70) + pixel loop / NaN rejection / tonemap (raytracing.cpp:96-123)
     total, rgb, counters = s.render(0, m["spp"], m["depth"], O.RNG_GLIBC)
     assert_bits(total * (1 / m["spp"]), g[tag + "_img_radiance"], "radiance")
