@@ -43,6 +43,10 @@ extern "C" {
 #define RT_PRIM_BOX      7  /* box      primitive.hpp:399-458, optionally inside rotatey and then translate (transform.hpp:9-121), as
                                cornell_box() builds it (demo.hpp:80-88): one leaf of the bvh.
                                data: minimum[3], maximum[3], sin_theta, cos_theta, target[3]                  */
+#define RT_PRIM_VOLUME   8  /* volume   primitive.hpp:329-396 around a sphere boundary: a constant-density medium; its material must be
+                               RT_MAT_FOG.  data: c[3], radius, neg_inv_d (= -1 / density).  The free-flight distance is drawn inside the
+                               intersection test (:373): such a primitive is never hit by rt_first_hit / rt_first_hit_fast, which have
+                               no random stream, and RT_FLAG_WAVEFRONT rejects scenes that contain one                                 */
 #define RT_PRIM_STRIDE  24  /* doubles per primitive record */
 #define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` */
 #define RT_PRIM_FLAG_ROTATEY 2   /* RT_PRIM_BOX: wrapped in rotatey (sin_theta, cos_theta as its constructor computes them) */
@@ -54,6 +58,7 @@ extern "C" {
 #define RT_MAT_DIELECTRIC 3 /* d[0] = ior                                        */
 #define RT_MAT_EMISSIVE   4 /* tex = emission                                    */
 #define RT_MAT_PHONG      5 /* tex = diffuse_map or -1; d[1..3] Kd, d[4..6] Ks, d[7..9] Ke, d[10..12] Tr, d[13] Ns, d[14] Ni */
+#define RT_MAT_FOG        6 /* tex = base_color (material.hpp:165-181); used by RT_PRIM_VOLUME */
 #define RT_MAT_STRIDE    16
 
 /* texture kinds (texture.hpp) and the layout of their RT_TEX_STRIDE doubles */

@@ -20,6 +20,8 @@ __device__ inline float  rt_sin(float v) { return sinf(v); }
 __device__ inline double rt_sin(double v) { return sin(v); }
 __device__ inline float  rt_cos(float v) { return cosf(v); }
 __device__ inline double rt_cos(double v) { return cos(v); }
+__device__ inline float  rt_log(float v) { return logf(v); }
+__device__ inline double rt_log(double v) { return log(v); }
 __device__ inline float  rt_acos(float v) { return acosf(v); }
 __device__ inline double rt_acos(double v) { return acos(v); }
 __device__ inline float  rt_atan2(float a, float b) { return atan2f(a, b); }
@@ -331,11 +333,54 @@ __device__ inline bool sphere_from_surface(const vec3<float>& center, const Ray<
     return true;
 }
 
-template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriShade<R>* aux, const Ray<R>& r, R t_min, R t_max, R& t)
+// volume::intersect (primitive.hpp:346-385) around a sphere boundary: g[0..3] centre, radius, g[4] = -1/density.  The two crossings
+// are the boundary's own intersect() over (-inf, inf) and over (t1 + 0.0001, inf); the free-flight distance is drawn INSIDE the
+// test (:373), so the position in the path's stream depends on which volumes the walk reaches, in which order.
+template <typename R> __device__ inline bool volume_crossings(const Prim<R>& p, const Ray<R>& r, R& t1, R& t2)
+{
+    const vec3<R> c(p.g[0], p.g[1], p.g[2]);
+    if (!sphere_t(c, p.g[3], r, -rt_inf<R>(), rt_inf<R>(), t1)) return false;                    // :349
+    return sphere_t(c, p.g[3], r, t1 + R(0.0001), rt_inf<R>(), t2);                              // :353
+}
+// fp32: t1 + 0.0001 is t1 itself once t1 > ~1000 (the radius-5000 haze sphere), so both roots are taken from one solve, with the
+// cancelling terms in fp64 as in sphere_t<float>
+template <> __device__ inline bool volume_crossings<float>(const Prim<float>& p, const Ray<float>& r, float& t1, float& t2)
+{
+    const double ox = (double) r.o.x - (double) p.g[0], oy = (double) r.o.y - (double) p.g[1], oz = (double) r.o.z - (double) p.g[2];
+    const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    const double a = dx * dx + dy * dy + dz * dz;
+    const double hb = ox * dx + oy * dy + oz * dz;
+    const double c = ox * ox + oy * oy + oz * oz - (double) p.g[3] * (double) p.g[3];
+    const double qd = hb * hb - a * c;
+    if (!(qd >= 0.0) || !(a > 0.0)) return false;
+    const float sq = sqrtf((float) qd), hbf = (float) hb, af = (float) a, cf = (float) c;
+    const float q = hbf < 0.0f ? sq - hbf : -(hbf + sq);
+    float r0 = q / af, r1 = q != 0.0f ? cf / q : r0;
+    t1 = fminf(r0, r1); t2 = fmaxf(r0, r1);
+    return t2 >= t1 + 0.0001f;
+}
+template <typename R> __device__ inline bool volume_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
+{
+    R t1, t2;
+    if (!g || !volume_crossings(p, r, t1, t2)) return false;           // no stream (first-hit entry points): a volume is never hit
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < R(0)) t1 = R(0);
+    const R ray_length = length(r.d);
+    const R inner_length = (t2 - t1) * ray_length;
+    const R intersect_distance = p.g[4] * rt_log(uniform<R>(*g));
+    if (intersect_distance > inner_length) return false;
+    t = t1 + intersect_distance / ray_length;
+    return true;
+}
+
+template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriShade<R>* aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
 {
     R a, b;
     if constexpr (sizeof(R) == sizeof(float)) {
-        if (p.id == r.from && p.kind() != RT_PRIM_BOX) {   // (a box is tested again, without the side the ray starts on: see box_t)
+        if (p.id == r.from && p.kind() != RT_PRIM_BOX && p.kind() != RT_PRIM_VOLUME) {   // (a box is tested again, without the side the ray starts on: see box_t;
+                                                                                          //  a path scattered inside a medium is still inside it)
             if (p.kind() == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
             if (p.kind() == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
             return false;
@@ -346,6 +391,7 @@ template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriS
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
     case RT_PRIM_BOX: return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr);
+    case RT_PRIM_VOLUME: return volume_t<R>(p, r, t_min, t_max, t, g);
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
@@ -408,6 +454,11 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
         box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
         break;
     }
+    case RT_PRIM_VOLUME:                                                    // primitive.hpp:379-383 (uv_coord is left as it was: 0 here)
+        h.pos = r.o + t * r.d;
+        h.normal = vec3<R>(R(1), R(0), R(0));
+        h.front = false;
+        break;
     default: {
         R oa, ob, ok, da, db, dk;
         plane_split(p.kind(), r.o, oa, ob, ok);
@@ -503,7 +554,7 @@ __device__ inline bool first_active_lane() { return (int) __lane_id() == __ffsll
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
 template <typename R, int kStats>   // 0: none, 1: count box/leaf tests, 2: counts + visit-order hash
 __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const TriShade<R>* __restrict__ aux,
-                                  const Ray<R>& r, R& t_hit, VisitStats* st)
+                                  const Ray<R>& r, R& t_hit, VisitStats* st, Rng* g = nullptr)
 {
     R closest = rt_inf<R>();
     const R t_min = consts<R>::tmin;
@@ -519,7 +570,7 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
         else {
             if (kStats) st->n_leaf++;
             R t;
-            if (prim_t(prims[op.prim], aux, r, t_min, closest, t)) { closest = t; hit = op.prim; }
+            if (prim_t(prims[op.prim], aux, r, t_min, closest, t, g)) { closest = t; hit = op.prim; }
             i++;
         }
     }
@@ -547,7 +598,7 @@ __device__ inline void slab2(const float* b, const vec3<float>& o, const vec3<fl
 
 template <int kStats>
 __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, const TriShade<float>* __restrict__ aux,
-                                      const Ray<float>& r, float& t_hit, uint32_t* stack, VisitStats* st)
+                                      const Ray<float>& r, float& t_hit, uint32_t* stack, VisitStats* st, Rng* g = nullptr)
 {
     const float t_min = consts<float>::tmin;
     float closest = rt_inf<float>();
@@ -583,7 +634,7 @@ __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Pri
             float t;
             if (kStats && first_active_lane()) st->w_leaf++;
             if (kStats) st->n_leaf++;
-            if (prim_t(prims[first + k], aux, r, t_min, closest, t)) { closest = t; hit = first + k; }
+            if (prim_t(prims[first + k], aux, r, t_min, closest, t, g)) { closest = t; hit = first + k; }
         }
         cur = (int32_t) stack[sp * 256]; sp--;
     }
@@ -706,6 +757,11 @@ template <typename R> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m
         spec = true;
         att = vec3<R>(R(1), R(1), R(1));
         dir = glass_dir(g, wi, h, m.d[0]);
+        return true;
+    case RT_MAT_FOG:                                                                        // material.hpp:174-180; pdf() stays the base class's 0 (:14)
+        spec = false;
+        dir = random_sphere<R>(g);
+        att = texc;
         return true;
     case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
@@ -959,8 +1015,8 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
             if (kCount && first_active_lane()) vs.w_bounce++;
             R t;
             int prim;
-            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.tris, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs);
-            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, sc.tris, ray, t, &vs);
+            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.tris, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs, &g);
+            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, sc.tris, ray, t, &vs, &g);
             bool done = true;
             if (prim >= 0) {
                 Hit<R> h;

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                     float t;
                     if (kCount && first_active_lane()) vs.w_leaf++;
                     if (kCount) vs.n_leaf++;
-                    if (prim_t(fprims[first + k], sc.tris, ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
+                    if (prim_t(fprims[first + k], sc.tris, ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
             }

@@ -73,6 +73,7 @@ struct rt_scene {
     DeviceScene<double> d64;
     DeviceScene<float> d32;
     int32_t n_lights = 0, n_prims = 0, n_ops = 0;
+    bool has_volume = false;                  // RT_PRIM_VOLUME present: needs the path's random stream during traversal
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
@@ -103,15 +104,17 @@ int validate(const rt_scene_desc* d)
     for (int i = 0; i < d->n_roots; i++) if (!code_ok(d->roots[i])) return fail(RT_EINVAL, "root code out of range");
     for (int i = 0; i < 2 * d->n_nodes; i++) if (!code_ok(d->node_child[i])) return fail(RT_EINVAL, "bvh child code out of range");
     for (int i = 0; i < d->n_prims; i++) {
-        if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown primitive kind");
+        if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_VOLUME) return fail(RT_EINVAL, "unknown primitive kind");
         if (d->prim_mat[i] < 0 || d->prim_mat[i] >= d->n_mats) return fail(RT_EINVAL, "primitive material index out of range");
+        if (d->prim_kind[i] == RT_PRIM_VOLUME && (d->mat_kind[d->prim_mat[i]] != RT_MAT_FOG || d->prim_flags[i] != 0))
+            return fail(RT_EINVAL, "a volume takes a fog material and no wrapper flags (primitive.hpp:332-344)");
     }
     for (int i = 0; i < d->n_lights; i++)
-        if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown light kind");
+        if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown light kind (a volume cannot be a light)");
     for (int i = 0; i < d->n_mats; i++) {
         int k = d->mat_kind[i], t = d->mat_tex[i];
-        if (k < RT_MAT_LAMBERTIAN || k > RT_MAT_PHONG) return fail(RT_EINVAL, "unknown material kind");
-        bool needs_tex = k == RT_MAT_LAMBERTIAN || k == RT_MAT_METAL || k == RT_MAT_EMISSIVE;
+        if (k < RT_MAT_LAMBERTIAN || k > RT_MAT_FOG) return fail(RT_EINVAL, "unknown material kind");
+        bool needs_tex = k == RT_MAT_LAMBERTIAN || k == RT_MAT_METAL || k == RT_MAT_EMISSIVE || k == RT_MAT_FOG;
         if (t >= d->n_tex || (needs_tex && t < 0)) return fail(RT_EINVAL, "material texture index out of range");
     }
     for (int i = 0; i < d->n_tex; i++) {
@@ -173,7 +176,7 @@ template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int k
 {
     std::memset(&p, 0, sizeof p);
     p.kf = kind | (flags << 8); p.mat = mat; p.id = id;
-    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : kind == RT_PRIM_BOX ? 8 : 5;
+    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_VOLUME ? 5 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : kind == RT_PRIM_BOX ? 8 : 5;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
     if (tri) {
         std::memset(tri, 0, sizeof *tri);
@@ -191,7 +194,7 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
     const double* g = d->prim_data + (size_t) i * RT_PRIM_STRIDE;
     auto sphere = [&](const double c[3], double r) { double lo[3] = { c[0] - r, c[1] - r, c[2] - r }, hi[3] = { c[0] + r, c[1] + r, c[2] + r }; b.grow(lo); b.grow(hi); };
     switch (d->prim_kind[i]) {
-    case RT_PRIM_SPHERE: sphere(g, std::fabs(g[3])); break;
+    case RT_PRIM_SPHERE: case RT_PRIM_VOLUME: sphere(g, std::fabs(g[3])); break;
     case RT_PRIM_MSPHERE: {
         double t0 = std::min(std::min(d->camera[22], d->camera[23]), std::min(g[6], 0.0));
         double t1 = std::max(std::max(d->camera[22], d->camera[23]), std::max(g[7], 0.0));
@@ -455,6 +458,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (e != hipSuccess) { delete s; return fail(RT_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e) + " (no HIP device: the HIP path is the only path)"); }
     if ((rc = build_device<double>(desc, f, s->d64)) || (rc = build_device<float>(desc, f, s->d32))) { rt_scene_destroy(s); return rc; }
     s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
+    for (int i = 0; i < desc->n_prims; i++) s->has_volume |= desc->prim_kind[i] == RT_PRIM_VOLUME;
     if (hipMalloc((void**) &s->counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
     if (const char* env = std::getenv("RT_LDS_LIMIT")) s->lds_limit = (size_t) std::strtoull(env, nullptr, 10);
@@ -500,6 +504,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
     a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised;
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
+        if (s->has_volume) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT: the extend kernel has no random stream, which a volume's intersection test draws from");
         int rc = wf_prepare(s);
         if (rc) return rc;
         unsigned long long c[8] = { 0 };

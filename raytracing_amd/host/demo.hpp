@@ -70,6 +70,26 @@ inline group deep_bounce_scene()
     return group(new bvh(grp, 0, 1));
 }
 
+// the sphere-bounded media of all_feature_test() (reference: src/cpp/demo.hpp:117-134: haze in a radius-5000 sphere, a glass ball
+// filled with blue fog, moving / glass / fuzzy-metal / mirror spheres) over a ground rect, plus a free-standing smoke ball
+inline group smoke_scene()
+{
+    group grp;
+    grp.add(new planexz(-1000, 1000, -1000, 1000, 0, new lambertian(vec3d(0.48, 0.83, 0.53))));
+    grp.add(new flip(new planexz(123, 423, 147, 412, 554, new emissive(vec3d(7, 7, 7)))));
+    grp.add(new msphere(vec3d(400, 400, 200), vec3d(430, 400, 200), 0, 1, 50, new lambertian(vec3d(0.7, 0.3, 0.1))));
+    grp.add(new sphere(vec3d(260, 150, 45), 50, new dielectric(1.5)));
+    grp.add(new sphere(vec3d(0, 150, 145), 50, new metal(vec3d(0.8, 0.8, 0.9), 1)));
+    grp.add(new volume(new sphere(vec3d(0, 0, 0), 5000, new dielectric(1.5)), 0.0002, vec3d(1, 1, 1)));
+    object* ball = new sphere(vec3d(360, 150, 145), 70, new dielectric(1.5));
+    grp.add(ball);
+    grp.add(new volume(ball, 0.2, vec3d(0.2, 0.4, 0.9)));
+    grp.add(new sphere(vec3d(400, 200, 400), 100, new lambertian(new checker(vec3d(0.2, 0.3, 0.1), vec3d(0.9, 0.9, 0.9)))));
+    grp.add(new sphere(vec3d(220, 280, 300), 50, new metal(vec3d(1, 1, 1), 0)));
+    grp.add(new volume(new sphere(vec3d(150, 100, 250), 80, new dielectric(1.5)), 0.01, vec3d(0.9, 0.9, 0.9)));
+    return grp;
+}
+
 // the scene of the reference's main() (reference: src/cpp/demo.hpp:63-91)
 inline group cornell_box()
 {

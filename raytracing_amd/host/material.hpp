@@ -1,5 +1,5 @@
 // raytracing_amd/host/material.hpp -- material classes (reference: src/cpp/material.hpp:9-312):
-// lambertian, metal, dielectric, emissive, phong.  Constructors and public fields match the reference so
+// lambertian, metal, dielectric, emissive, fog, phong.  Constructors and public fields match the reference so
 // scene code compiles unchanged; shading/pdf/emit run on the GPU (csrc/rt_device.h mat_shading / mat_pdf / mat_emit).
 #pragma once
 
@@ -52,6 +52,15 @@ public:
     emissive(const vec3d& color) : emission(new constant(color)) {}
     bool has_emission() const override { return true; }
     void flatten(flattener& f, int id) const override { int t = f.texture_id(emission); slot(f, id, RT_MAT_EMISSIVE, t); }
+};
+
+// the medium of a `volume` (reference: src/cpp/material.hpp:165-181): scatters into a uniformly random direction
+class fog : public material {
+public:
+    texture* base_color;
+    fog(vec3d color) : base_color(new constant(color)) {}
+    fog(texture* tex) : base_color(tex) {}
+    void flatten(flattener& f, int id) const override { int t = f.texture_id(base_color); slot(f, id, RT_MAT_FOG, t); }
 };
 
 // the MTL material every OBJ face gets (reference loader.hpp:160)

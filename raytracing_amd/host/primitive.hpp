@@ -1,6 +1,8 @@
 // raytracing_amd/host/primitive.hpp -- sphere, msphere, planexy/xz/yz
-// (reference: src/cpp/primitive.hpp:13-326; `volume` and `box` are outside this round's hot-path scope).
+// (reference: src/cpp/primitive.hpp:13-458), `box`, and `volume` around a sphere boundary.
 #pragma once
+
+#include <stdexcept>
 
 #include "material.hpp"
 #include "object.hpp"
@@ -50,6 +52,28 @@ public:
         out.data[6] = start; out.data[7] = end; out.data[8] = radius;
         return true;
     }
+};
+
+// constant-density medium inside `surface` (reference: src/cpp/primitive.hpp:329-396).  The core takes sphere boundaries
+// (what all_feature_test() builds, demo.hpp:125-130); the boundary's own material is never used by the reference either.
+class volume : public object {
+public:
+    volume(object* surface_, double density, texture* tex) : surface(surface_), mat(new fog(tex)), neg_inv_d(-1.0 / density) {}
+    volume(object* surface_, double density, const vec3d& color) : surface(surface_), mat(new fog(color)), neg_inv_d(-1.0 / density) {}
+    bool bounding_box(double start, double end, aabb& bbox) const override { return surface->bounding_box(start, end, bbox); }
+    bool leaf_record(flat_leaf& out) const override
+    {
+        const sphere* s = dynamic_cast<const sphere*>(surface);
+        if (!s) throw std::runtime_error("volume: the boundary must be a sphere");
+        out.kind = RT_PRIM_VOLUME; out.mat = mat;
+        for (int k = 0; k < 3; k++) out.data[k] = s->center[k];
+        out.data[3] = s->radius; out.data[4] = neg_inv_d;
+        return true;
+    }
+private:
+    object* surface;
+    material* mat;
+    double neg_inv_d;
 };
 
 // shared body of the three axis-aligned rectangles; `axis` is the constant coordinate

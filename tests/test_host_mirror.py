@@ -31,13 +31,13 @@ def desc_to_rows(d):
         if k in (2, 3):
             row[1] = m[0]
         if k != 3 and t >= 0:
-            tex_row(t, row[2:])
+            tex_row(t, row[2:])          # (fog, kind 6: base_color, like lambertian)
         if k == 5:
             row[9:21] = m[1:13]; row[21] = m[13]; row[22] = m[14]
 
     def leaf_row(kind, flags, mat, data, r):
         r[0] = kind; r[1] = flags & 1
-        ng = {1: 4, 2: 9, 6: 24, 7: 11}.get(kind, 5)
+        ng = {1: 4, 2: 9, 6: 24, 7: 11, 8: 5}.get(kind, 5)
         r[4:4 + ng] = data[:ng]
         if kind == 7:
             r[3] = flags & 6      # rotatey / translate wrappers around the box
@@ -78,6 +78,7 @@ CASES = {
     "c0_seed7": ("c0", lambda gd, m: HostScene.random_spheres(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "mixed": ("mixed", lambda gd, m: HostScene.mixed(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
     "cornell": ("cornell", lambda gd, m: HostScene.cornell(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
+    "smoke": ("smoke", lambda gd, m: HostScene.smoke(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "obj": ("obj", lambda gd, m: HostScene.obj(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"]),
             lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
 }
