@@ -134,6 +134,8 @@ def main():
         "cornell": (["cornell", 1, 56, 56, 16, 10], dict(seed=1, width=56, height=56, spp=16, depth=10)),
         # volume / fog: sphere-bounded media of all_feature_test() (demo.hpp:117-134) over a ground rect
         "smoke": (["smoke", 2, 64, 48, 16, 12], dict(seed=2, width=64, height=48, spp=16, depth=12)),
+        # all_feature_test() (demo.hpp:94-143): 400 boxes, media, a failed image texture, translate(rotatey(bvh(1000 spheres)))
+        "features": (["features", 4, 48, 32, 4, 10], dict(seed=4, width=48, height=32, spp=4, depth=10)),
     }
     only = sys.argv[1:]          # optional: names of the fixtures to (re)generate
     for name, (args, meta) in jobs.items():

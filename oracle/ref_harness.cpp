@@ -99,7 +99,7 @@ struct tree_dump {
         unwrap(e);
         pre.push_back(e);
         if (!first.count(o)) first[o] = idx;
-        if (const bvh* b = dynamic_cast<const bvh*>(o)) {
+        if (const bvh* b = dynamic_cast<const bvh*>(e.base)) {          // also a bvh under translate / rotatey (an instance)
             int l = walk(b->left);
             int r = walk(b->right);
             pre[idx].left = l;
@@ -156,6 +156,7 @@ struct tree_dump {
                 r[0] = K_NODE;
                 for (int k = 0; k < 3; k++) { g[k] = b->bbox.min()[k]; g[3 + k] = b->bbox.max()[k]; }
                 g[6] = e.left; g[7] = e.right;
+                if (e.xf) { r[3] = e.xf; g[8] = e.sin_t; g[9] = e.cos_t; for (int k = 0; k < 3; k++) g[10 + k] = e.target[k]; }
             } else if (const sphere* s = dynamic_cast<const sphere*>(e.base)) {
                 r[0] = K_SPHERE; for (int k = 0; k < 3; k++) g[k] = s->center[k]; g[3] = s->radius; mat = s->mat;
             } else if (const msphere* s = dynamic_cast<const msphere*>(e.base)) {
@@ -319,6 +320,22 @@ static built_scene* build_smoke(int w, int h)
     grp.add(new volume(new sphere(vec3d(150, 100, 250), 80, new dielectric(1.5)), 0.01, vec3d(0.9, 0.9, 0.9)));
     b->scn->add_object(grp);
     b->scn->add_light(new flip(new planexz(123, 423, 147, 412, 554, new emissive(vec3d(7, 7, 7)))));
+    b->scn->set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(w) / h, 0, 10, 0, 1));
+    b->scn->build_bvh();
+    b->root = b->scn->objects.content()[0];
+    b->td.walk(b->root);
+    return b;
+}
+
+// all_feature_test() (demo.hpp:94-143) as the reference builds it, under a light and a camera of the harness' choosing (the
+// reference's main() never renders this scene).  scene::build_bvh() wraps the single object in a span-1 bvh: both children
+// are the same subtree, and the reference walks it twice.
+static built_scene* build_features(int w, int h)
+{
+    built_scene* b = new built_scene();
+    b->scn = new scene(w, h);
+    b->scn->add_object(all_feature_test());
+    b->scn->add_light(new planexz(123, 423, 147, 412, 554, new emissive(vec3d(7, 7, 7))));
     b->scn->set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(w) / h, 0, 10, 0, 1));
     b->scn->build_bvh();
     b->root = b->scn->objects.content()[0];
@@ -671,6 +688,17 @@ int main(int argc, char** argv)
         double lo[3] = { -100, 1, -100 }, hi[3] = { 554, 554, 554 };
         do_firsthit("smoke", b, 32, 1024, lo, hi, false);      // volume::intersect draws from rand() during these walks too
         do_image("smoke", b, w, h, spp, depth);
+    }
+    else if (mode == "features") {      // features <seed> <w> <h> <spp> <depth>
+        unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+        srand(seed);
+        built_scene* b = build_features(w, h);
+        dump_f64("features_tree", b->td.rows());
+        dump_lights("features_lights", *b->scn);
+        dump_camera("features_camera", b->scn->render_camera);
+        double lo[3] = { -200, 1, -200 }, hi[3] = { 554, 554, 600 };
+        do_firsthit("features", b, 32, 1024, lo, hi, false);
+        do_image("features", b, w, h, spp, depth);
     }
     else if (mode == "time_c0") {       // time_c0 <seed> <w> <h> <spp> <depth> : throughput of the real reference, 1 thread
         unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);

@@ -200,13 +200,14 @@ typedef struct { int kind; double d[ORC_TEX_STRIDE]; const uint8_t* pixels; int 
 typedef struct { int kind; int tex; double d[ORC_MAT_STRIDE]; } orc_mat;
 /* mat d[]: [0] roughness | ior ; phong: [1..3] Kd [4..6] Ks [7..9] Ke [10..12] Tr [13] Ns [14] Ni */
 
-enum { O_BVH = 100, O_FLIP = 101 };
+enum { O_BVH = 100, O_FLIP = 101, O_TRANSLATE = 102, O_ROTATEY = 103 };   /* translate: g[0..2] target; rotatey: g[0] sin, g[1] cos, g[2] has_bbox, box */
 typedef struct orc_obj {
     int kind;                 /* ORC_SPHERE.. | O_BVH | O_FLIP */
     int id;                   /* prim id (insertion order into scene.objects), -1 for bvh nodes / light-only objects */
     int mat;
     double g[ORC_PRIM_STRIDE];
-    struct orc_obj *l, *r;    /* bvh children; flip: l = inner */
+    struct orc_obj *l, *r;    /* bvh children; flip / translate / rotatey / volume: l = inner */
+    int first_entry;          /* first pre-order index (pre-order view), -1 until walked */
     aabb box;                 /* bvh */
 } orc_obj;
 
@@ -568,6 +569,32 @@ static int obj_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g)
         x->leaf = o;
         return 1;
     case O_BVH: return bvh_hit(o, r, x, g);
+    case O_TRANSLATE: {                                                 /* transform.hpp:18-28 */
+        const v3 target = V(o->g[0], o->g[1], o->g[2]);
+        ray off = mkray(vsub(r->o, target), r->d, r->time, r->t_min, r->t_max);
+        if (!obj_hit(o->l, &off, x, g)) return 0;
+        x->pos = vadd(x->pos, target);
+        set_face_normal(x, &off, x->normal);
+        return 1;
+    }
+    case O_ROTATEY: {                                                   /* transform.hpp:81-110 */
+        const double sn = o->g[0], cs = o->g[1];
+        v3 origin = r->o, direction = r->d;
+        origin.x = cs * r->o.x - sn * r->o.z;
+        origin.z = sn * r->o.x + cs * r->o.z;
+        direction.x = cs * r->d.x - sn * r->d.z;
+        direction.z = sn * r->d.x + cs * r->d.z;
+        ray rot = mkray(origin, direction, r->time, r->t_min, r->t_max);
+        if (!obj_hit(o->l, &rot, x, g)) return 0;
+        v3 position = x->pos, normal = x->normal;
+        position.x = cs * x->pos.x + sn * x->pos.z;
+        position.z = -sn * x->pos.x + cs * x->pos.z;
+        normal.x = cs * x->normal.x + sn * x->normal.z;
+        normal.z = -sn * x->normal.x + cs * x->normal.z;
+        x->pos = position;
+        set_face_normal(x, &rot, normal);
+        return 1;
+    }
     }
     return 0;
 }
@@ -634,6 +661,13 @@ static int obj_bbox(const orc_obj* o, double start, double end, aabb* out)
     case ORC_VOLUME: return obj_bbox(o->l, start, end, out);            /* primitive.hpp:387-390 */
     case O_FLIP: return obj_bbox(o->l, start, end, out);                /* transform.hpp:138-141 */
     case O_BVH: *out = o->box; return 1;                                /* bvh.hpp:70-74 */
+    case O_TRANSLATE: {                                                 /* transform.hpp:30-37 */
+        if (!obj_bbox(o->l, start, end, out)) return 0;
+        v3 target = V(o->g[0], o->g[1], o->g[2]);
+        out->mn = vadd(out->mn, target); out->mx = vadd(out->mx, target);
+        return 1;
+    }
+    case O_ROTATEY: *out = o->box; return (int) o->g[2];                /* transform.hpp:112-116 */
     }
     return 0;
 }
@@ -729,7 +763,7 @@ static void merge_sort_desc(orc_obj** a, double* key, int n, orc_obj** ta, doubl
 static orc_obj* new_obj(int kind)
 {
     orc_obj* o = (orc_obj*) calloc(1, sizeof(orc_obj));
-    o->kind = kind; o->id = -1; o->mat = -1;
+    o->kind = kind; o->id = -1; o->mat = -1; o->first_entry = -1;
     return o;
 }
 
@@ -1098,6 +1132,82 @@ orc_scene* orc_build_cornell(int width, int height, unsigned seed)
     return s;
 }
 
+static orc_obj* mk_translate(orc_obj* inner, v3 target)
+{ orc_obj* o = new_obj(O_TRANSLATE); o->l = inner; o->g[0] = target.x; o->g[1] = target.y; o->g[2] = target.z; return o; }
+static orc_obj* mk_rotatey(orc_obj* inner, double angle)                /* transform.hpp:47-79 */
+{
+    orc_obj* o = new_obj(O_ROTATEY); o->l = inner;
+    double arc = angle * ORC_PI / 180;                                  /* util.hpp:24-27 */
+    o->g[0] = sin(arc); o->g[1] = cos(arc);
+    aabb b; memset(&b, 0, sizeof b);
+    o->g[2] = obj_bbox(inner, 0, 1, &b);
+    double mn[3] = { ORC_INF, ORC_INF, ORC_INF }, mx[3] = { -ORC_INF, -ORC_INF, -ORC_INF };
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+        double x = i * b.mx.x + (1 - i) * b.mn.x;
+        double y = j * b.mx.y + (1 - j) * b.mn.y;
+        double z = k * b.mx.z + (1 - k) * b.mn.z;
+        double t[3] = { o->g[1] * x + o->g[0] * z, y, -o->g[0] * x + o->g[1] * z };
+        for (int l = 0; l < 3; l++) { mn[l] = fmin(mn[l], t[l]); mx[l] = fmax(mx[l], t[l]); }
+    }
+    o->box.mn = V(mn[0], mn[1], mn[2]); o->box.mx = V(mx[0], mx[1], mx[2]);
+    return o;
+}
+/* a leaf that gets a primitive id but is not (yet) a member of scene.objects: the contents of a nested bvh */
+static orc_obj* detached_sphere(orc_scene* s, v3 c, double radius, int mat)
+{
+    orc_obj* o = new_obj(ORC_SPHERE); o->mat = mat; o->g[0] = c.x; o->g[1] = c.y; o->g[2] = c.z; o->g[3] = radius;
+    o->id = s->n_prims;
+    push(&s->prims, &s->n_prims, &s->cap_prims, o);
+    return o;
+}
+
+/* all_feature_test() (demo.hpp:94-143) under a light and a camera (the reference never renders it: raytracing.cpp:84 picks
+ * cornell_box()).  As there: 400 ground boxes, rect light (not flipped: it shines upwards), moving / glass / fuzzy-metal
+ * spheres, haze and blue-fog volumes, a sphere whose image texture fails to load (cyan, texture.hpp:97-99), a mirror sphere,
+ * and translate(rotatey(bvh(1000 spheres))) -- all inside bvh(grp, 0, 1).  Same scene as ref_harness.cpp build_features. */
+orc_scene* orc_build_features(int width, int height, unsigned seed)
+{
+    orc_scene* s = orc_scene_new(width, height, seed);
+    orc_rng* g = &s->rng;
+    int white = orc_mat_lambertian(s, orc_tex_constant(s, 0.73, 0.73, 0.73));
+    int ground = orc_mat_lambertian(s, orc_tex_constant(s, 0.48, 0.83, 0.53));
+    int light = orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7));
+    double zero3[3] = { 0, 0, 0 };
+    for (int i = 0; i < 20; i++) {
+        for (int j = 0; j < 20; j++) {
+            double w = 100, x0 = -1000 + i * w, z0 = -1000 + j * w, y0 = 0, x1 = x0 + w, z1 = z0 + w;
+            double y1 = rnd_range(g, 1, 101);
+            double mn[3] = { x0, y0, z0 }, mx[3] = { x1, y1, z1 };
+            orc_add_box(s, mn, mx, 0, 0, 1, zero3, ground, 0, 0);
+        }
+    }
+    orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, light, 0, 0);
+    double m0[3] = { 400, 400, 200 }, m1[3] = { 500, 400, 200 };
+    orc_add_msphere(s, m0, m1, 0, 1, 50, orc_mat_lambertian(s, orc_tex_constant(s, 0.7, 0.3, 0.1)), 0, 0);
+    double c1[3] = { 260, 150, 45 }, c2[3] = { 0, 150, 145 }, c3[3] = { 360, 150, 145 }, c4[3] = { 400, 200, 400 }, c5[3] = { 220, 280, 300 };
+    orc_add_sphere(s, c1, 50, orc_mat_dielectric(s, 1.5), 0, 0);
+    orc_add_sphere(s, c2, 50, orc_mat_metal(s, orc_tex_constant(s, 0.8, 0.8, 0.9), 1), 0, 0);
+    orc_add_volume(s, zero3, 5000, 0.0002, orc_mat_fog(s, orc_tex_constant(s, 1, 1, 1)), 0);
+    orc_add_sphere(s, c3, 70, orc_mat_dielectric(s, 1.5), 0, 0);
+    orc_add_volume(s, c3, 70, 0.2, orc_mat_fog(s, orc_tex_constant(s, 0.2, 0.4, 0.9)), 0);
+    orc_add_sphere(s, c4, 100, orc_mat_lambertian(s, orc_tex_image(s, NULL, 0, 0, 0, 0)), 0, 0);
+    orc_add_sphere(s, c5, 50, orc_mat_metal(s, orc_tex_constant(s, 1, 1, 1), 0), 0, 0);
+    orc_obj** cloud = (orc_obj**) malloc(sizeof(orc_obj*) * 1000);
+    for (int i = 0; i < 1000; i++) cloud[i] = detached_sphere(s, rnd_vec(g, 0, 165), 10, white);
+    orc_obj* nested = bvh_build(g, cloud, 0, 1000, 0, 0);               /* new bvh(vol_boxes): start = end = 0 */
+    free(cloud);
+    orc_obj* inst = mk_translate(mk_rotatey(nested, 15), V(-100, 270, 395));
+    push(&s->objects, &s->n_objects, &s->cap_objects, inst);
+    orc_obj* root = bvh_build(g, s->objects, 0, s->n_objects, 0, 1);   /* demo.hpp:141 */
+    s->objects[0] = root;
+    s->n_objects = 1;
+    orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 0, 1);
+    double pos[3] = { 478, 278, -600 }, at[3] = { 278, 278, 0 }, up[3] = { 0, 1, 0 };
+    orc_set_camera(s, pos, at, up, 40, 0, 10, 0, 1);
+    orc_build_bvh(s);
+    return s;
+}
+
 /* same scene as ref_harness.cpp build_smoke: sphere-bounded media (primitive.hpp:329-396) with fog (material.hpp:165-181) */
 orc_scene* orc_build_smoke(int width, int height, unsigned seed)
 {
@@ -1134,10 +1244,14 @@ static int pre_walk(orc_scene* s, const orc_obj* o, int* cap)
         s->pre_right = (int*) realloc(s->pre_right, sizeof(int) * *cap);
     }
     int idx = s->n_pre++;
-    s->pre[idx] = o; s->pre_left[idx] = s->pre_right[idx] = -1; s->pre_first[idx] = idx;
-    if (o->kind == O_BVH) {
-        int l = pre_walk(s, o->l, cap);
-        int r = pre_walk(s, o->r, cap);
+    s->pre[idx] = o; s->pre_left[idx] = s->pre_right[idx] = -1;
+    if (o->first_entry < 0) ((orc_obj*) o)->first_entry = idx;        /* an object reached twice (both children of a span-1 node) */
+    s->pre_first[idx] = o->first_entry;
+    const orc_obj* base = o;                                            /* ref_harness.cpp tree_dump::walk: a wrapped bvh is dumped too */
+    while (base->kind == O_FLIP || base->kind == O_TRANSLATE || base->kind == O_ROTATEY) base = base->l;
+    if (base->kind == O_BVH) {
+        int l = pre_walk(s, base->l, cap);
+        int r = pre_walk(s, base->r, cap);
         s->pre_left[idx] = l; s->pre_right[idx] = r;
     }
     return idx;
@@ -1154,9 +1268,6 @@ static void ensure_pre(const orc_scene* cs)
     s->n_pre = 0;
     s->root_entry = (int*) malloc(sizeof(int) * (s->n_objects + 1));
     for (int i = 0; i < s->n_objects; i++) { s->root_entry[i] = s->n_pre; pre_walk(s, s->objects[i], &cap); }
-    /* first occurrence per object: only duplicates are the two children of a span-1 node (adjacent entries) */
-    for (int i = 1; i < s->n_pre; i++)
-        if (s->pre[i] == s->pre[i - 1]) s->pre_first[i] = s->pre_first[i - 1];
 }
 
 static void put_tex_row(const orc_scene* s, int ti, double* row)
@@ -1180,8 +1291,13 @@ static void put_mat_row(const orc_scene* s, int mi, double* row)
 }
 static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int left, int right)
 {
-    const orc_obj* base = o; int flipped = 0;
-    while (base->kind == O_FLIP) { base = base->l; flipped ^= 1; }
+    const orc_obj* base = o; int flipped = 0, xf = 0; double sn = 0, cs = 1; v3 target = V(0, 0, 0);
+    for (;;) {                                                          /* ref_harness.cpp unwrap(): outermost first */
+        if (base->kind == O_FLIP) { base = base->l; flipped ^= 1; }
+        else if (base->kind == O_TRANSLATE) { target = V(base->g[0], base->g[1], base->g[2]); xf |= 4; base = base->l; }
+        else if (base->kind == O_ROTATEY) { sn = base->g[0]; cs = base->g[1]; xf |= 2; base = base->l; }
+        else break;
+    }
     r[1] = flipped;
     double* g = r + 4; double* m = r + 30;
     if (base->kind == O_BVH) {
@@ -1189,6 +1305,7 @@ static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int lef
         g[0] = base->box.mn.x; g[1] = base->box.mn.y; g[2] = base->box.mn.z;
         g[3] = base->box.mx.x; g[4] = base->box.mx.y; g[5] = base->box.mx.z;
         g[6] = left; g[7] = right;
+        if (xf) { r[3] = xf; g[8] = sn; g[9] = cs; g[10] = target.x; g[11] = target.y; g[12] = target.z; }
         return;
     }
     r[0] = base->kind;
@@ -1323,7 +1440,7 @@ void orc_first_hit(const orc_scene* s, int n, const double* rays, int32_t* entry
             if (rewalk(s, s->root_entry[k], &rr, &tmp, &st, (orc_rng*) &s->rng)) {   /* volumes draw from the scene's stream, like the harness' walk */ has = 1; closest = tmp.t; x = tmp; } else st.hit_entry = he;
         }
         entry_first[i] = has ? s->pre_first[st.hit_entry] : -1;
-        prim_id[i] = has ? s->pre[st.hit_entry]->id : -1;
+        prim_id[i] = has ? (x.leaf ? x.leaf->id : s->pre[st.hit_entry]->id) : -1;   /* the leaf itself, also inside an instance */
         t[i] = has ? x.t : 0.0;
         nbox[i] = st.nbox; nleaf[i] = st.nleaf; hash[i] = st.hash;
         front[i] = has ? x.front : -1;

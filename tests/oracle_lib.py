@@ -35,7 +35,8 @@ def lib():
         L.orc_build_mixed.restype = C.c_void_p
         L.orc_build_cornell.restype = C.c_void_p
         L.orc_build_smoke.restype = C.c_void_p
-        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke"):
+        L.orc_build_features.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke", "orc_build_features"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         _lib = L
     return _lib
@@ -69,6 +70,11 @@ class Scene:
     def smoke(cls, width, height, seed=1):
         """sphere-bounded media (volume / fog) of all_feature_test() over a ground rect: ref_harness.cpp build_smoke"""
         return cls(lib().orc_build_smoke(width, height, seed), width, height)
+
+    @classmethod
+    def features(cls, width, height, seed=1):
+        """all_feature_test() (demo.hpp:94-143) under a light and a camera: ref_harness.cpp build_features"""
+        return cls(lib().orc_build_features(width, height, seed), width, height)
 
     @classmethod
     def cornell(cls, width, height, seed=1):
