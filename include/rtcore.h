@@ -48,6 +48,7 @@ extern "C" {
                                intersection test (:373): such a primitive is never hit by rt_first_hit / rt_first_hit_fast, which have
                                no random stream, and RT_FLAG_WAVEFRONT rejects scenes that contain one                                 */
 #define RT_PRIM_STRIDE  24  /* doubles per primitive record */
+#define RT_XFORM_STRIDE  6  /* doubles per instance transform */
 #define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` */
 #define RT_PRIM_FLAG_ROTATEY 2   /* RT_PRIM_BOX: wrapped in rotatey (sin_theta, cos_theta as its constructor computes them) */
 #define RT_PRIM_FLAG_TRANSLATE 4 /* RT_PRIM_BOX: wrapped (outermost) in translate(target) */
@@ -88,6 +89,15 @@ typedef struct rt_scene_desc {
     /* camera after setup_camera (camera.hpp:46-60): position[3], left_bottom[3], horizontal[3], vertical[3],
      * u[3], v[3], w[3], lens_radius, shutter_start, shutter_end */
     double camera[24];
+    /* instances: a bvh (or a single primitive) wrapped in rotatey and / or translate (transform.hpp:9-121), as all_feature_test()
+     * builds (demo.hpp:136-140).  Members keep their object-space geometry -- node boxes and primitive records -- and name their
+     * transform; rays are taken into that frame for every test and hit records come back out through both wrappers'
+     * set_face_normal calls.  RT_PRIM_BOX keeps carrying its own wrappers in its record (prim_xform -1).  n_xforms == 0: the two
+     * index arrays may be NULL. */
+    int32_t n_xforms; const double* xform_data;  /* n_xforms x RT_XFORM_STRIDE: sin_theta, cos_theta, target[3], wrappers
+                                                     (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE; translate is the outer one) */
+                      const int32_t* node_xform; /* n_nodes: transform index, -1 = world space */
+                      const int32_t* prim_xform; /* n_prims: transform index, -1 = world space */
 } rt_scene_desc;
 
 /* precision / traversal mode of rt_render */

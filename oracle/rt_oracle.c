@@ -1357,23 +1357,50 @@ void orc_camera_fields(const orc_scene* s, double out[24])
 }
 
 /* ------------------------------------------------------------------ flattened export */
-static int count_nodes(const orc_obj* o) { return o->kind == O_BVH ? 1 + count_nodes(o->l) + count_nodes(o->r) : 0; }
+/* one walk serves the counts (all outputs NULL) and the export.  A bvh (or leaf) wrapped in translate(rotatey(.)), rotatey(.) or
+ * translate(.) becomes an instance: its nodes and leaves keep their object-space geometry and name the transform. */
+typedef struct { double* bbox; int32_t* child; double* xform_data; int32_t* node_xform; int32_t* prim_xform; int next, n_xf, cur; } exp_ctx;
+static int export_node(const orc_obj* o, exp_ctx* c)
+{
+    if (o->kind == O_TRANSLATE || o->kind == O_ROTATEY) {
+        int fl = 0; double sn = 0, cs = 1; v3 target = V(0, 0, 0);
+        if (o->kind == O_TRANSLATE) { target = V(o->g[0], o->g[1], o->g[2]); fl |= 4; o = o->l; }
+        if (o->kind == O_ROTATEY) { sn = o->g[0]; cs = o->g[1]; fl |= 2; o = o->l; }
+        if (o->kind == O_TRANSLATE || o->kind == O_ROTATEY || c->cur >= 0) { fprintf(stderr, "oracle export: only translate(rotatey(x)) nesting, one level\n"); abort(); }
+        int id = c->n_xf++;
+        if (c->xform_data) { double* x = c->xform_data + 6 * id; x[0] = sn; x[1] = cs; x[2] = target.x; x[3] = target.y; x[4] = target.z; x[5] = fl; }
+        c->cur = id;
+        int code = export_node(o, c);
+        c->cur = -1;
+        return code;
+    }
+    if (o->kind != O_BVH) {
+        if (c->prim_xform && c->cur >= 0) c->prim_xform[o->id] = c->cur;
+        return ~o->id;
+    }
+    int idx = c->next++;
+    if (c->bbox) { put3(c->bbox + 6 * idx, o->box.mn); put3(c->bbox + 6 * idx + 3, o->box.mx); }
+    if (c->node_xform) c->node_xform[idx] = c->cur;
+    int l = export_node(o->l, c);
+    int r = (o->r == o->l && o->l->kind != O_BVH && o->l->kind != O_TRANSLATE && o->l->kind != O_ROTATEY) ? l : export_node(o->r, c);
+    if (c->child) { c->child[2 * idx] = l; c->child[2 * idx + 1] = r; }
+    return idx;
+}
 void orc_export_counts(const orc_scene* s, int32_t c[8])
 {
-    int nn = 0;
-    for (int i = 0; i < s->n_objects; i++) nn += count_nodes(s->objects[i]);
-    c[0] = nn; c[1] = s->n_prims; c[2] = s->n_mats; c[3] = s->n_texs; c[4] = s->n_lights; c[5] = s->n_objects;
-    c[6] = s->n_pixel_bytes; c[7] = 0;
+    exp_ctx x; memset(&x, 0, sizeof x); x.cur = -1;
+    for (int i = 0; i < s->n_objects; i++) export_node(s->objects[i], &x);
+    c[0] = x.next; c[1] = s->n_prims; c[2] = s->n_mats; c[3] = s->n_texs; c[4] = s->n_lights; c[5] = s->n_objects;
+    c[6] = s->n_pixel_bytes; c[7] = x.n_xf;
 }
-static int export_node(const orc_obj* o, double* bbox, int32_t* child, int* next)
+/* instance transforms of the flattened scene: xform_data n_xforms x 6 (sin, cos, target, wrappers), node_xform / prim_xform -1 = none */
+void orc_export_instances(const orc_scene* s, double* xform_data, int32_t* node_xform, int32_t* prim_xform)
 {
-    if (o->kind != O_BVH) return ~o->id;
-    int idx = (*next)++;
-    put3(bbox + 6 * idx, o->box.mn); put3(bbox + 6 * idx + 3, o->box.mx);
-    int l = export_node(o->l, bbox, child, next);
-    int r = (o->r == o->l && o->l->kind != O_BVH) ? l : export_node(o->r, bbox, child, next);
-    child[2 * idx] = l; child[2 * idx + 1] = r;
-    return idx;
+    int32_t c[8]; orc_export_counts(s, c);
+    for (int i = 0; i < c[0]; i++) node_xform[i] = -1;
+    for (int i = 0; i < c[1]; i++) prim_xform[i] = -1;
+    exp_ctx x; memset(&x, 0, sizeof x); x.cur = -1; x.xform_data = xform_data; x.node_xform = node_xform; x.prim_xform = prim_xform;
+    for (int i = 0; i < s->n_objects; i++) export_node(s->objects[i], &x);
 }
 static void export_prim(const orc_obj* o, int32_t* kind, int32_t* flags, int32_t* mat, double* data)
 {
@@ -1390,8 +1417,8 @@ void orc_export(const orc_scene* s, double* node_bbox, int32_t* node_child, int3
                 int32_t* tex_kind, double* tex_data, uint8_t* tex_pixels,
                 int32_t* light_kind, int32_t* light_flags, int32_t* light_mat, double* light_data, double cam[24])
 {
-    int next = 0;
-    for (int i = 0; i < s->n_objects; i++) roots[i] = export_node(s->objects[i], node_bbox, node_child, &next);
+    exp_ctx x; memset(&x, 0, sizeof x); x.cur = -1; x.bbox = node_bbox; x.child = node_child;
+    for (int i = 0; i < s->n_objects; i++) roots[i] = export_node(s->objects[i], &x);
     for (int i = 0; i < s->n_prims; i++) export_prim(s->prims[i], prim_kind + i, prim_flags + i, prim_mat + i, prim_data + (size_t) i * ORC_PRIM_STRIDE);
     for (int i = 0; i < s->n_mats; i++) { mat_kind[i] = s->mats[i].kind; mat_tex[i] = s->mats[i].tex; memcpy(mat_data + i * ORC_MAT_STRIDE, s->mats[i].d, sizeof(double) * ORC_MAT_STRIDE); }
     for (int i = 0; i < s->n_texs; i++) { tex_kind[i] = s->texs[i].kind; memcpy(tex_data + i * ORC_TEX_STRIDE, s->texs[i].d, sizeof(double) * ORC_TEX_STRIDE); }

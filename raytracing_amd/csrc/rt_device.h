@@ -62,11 +62,14 @@ template <typename R> struct alignas(8) Op {
 // 48 B in fp32: three 16-byte loads fetch any primitive.
 template <typename R> struct alignas(16) Prim {
     R g[9];
-    int32_t kf;                     // kind | flags << 8
+    int32_t kf;                     // kind | flags << 8 | (instance transform + 1) << 16
     int32_t mat, id;                // id: primitive id (index into tris[]); records may be stored in any order
     __host__ __device__ int kind() const { return kf & 0xff; }
-    __host__ __device__ int flags() const { return kf >> 8; }
+    __host__ __device__ int flags() const { return (kf >> 8) & 0xff; }
+    __host__ __device__ int xform() const { return (int) (((uint32_t) kf) >> 16) - 1; }   // instance transform (Scene::xforms), -1: none
 };
+// rotatey / translate around an instance (transform.hpp:9-121): sin, cos as the rotatey constructor computes them, translate target
+template <typename R> struct Xform { R sn, cs, t[3]; int32_t flags; };
 // Fast-mode BVH node (64 B, one cache line): both children's boxes live in the parent, so one fetch decides both.
 // Child code c >= 0: inner node c; c < 0: leaf, ~c = first_record * 8 + (count - 1) into Scene::fprims (<= 8 records).
 struct alignas(16) BNode {
@@ -96,6 +99,11 @@ struct alignas(16) QNode {
 template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
 template <typename R> struct Mat { int32_t kind, tex; R d[16]; };
 template <typename R> struct Tex { int32_t kind, a, b, ch, color_based; uint32_t offset; R rgb[3]; R pad; };
+// what a primitive test may need besides the hot record: side records by primitive id, instance transforms
+template <typename R> struct Side {
+    const TriShade<R>* tris; const Xform<R>* xforms;
+    __device__ const TriShade<R>& operator[](int i) const { return tris[i]; }
+};
 template <typename R> struct Camera { vec3<R> pos, left_bottom, horizontal, vertical, u, v; R lens_radius, s0, s1; };
 
 template <typename R> struct Scene {
@@ -109,7 +117,9 @@ template <typename R> struct Scene {
     int32_t need_uv;                  // some material reads uv (image texture)
     const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
     const QNode* qnodes;              // the same tree, 32-byte quantised nodes
+    const Xform<R>* xforms;           // instance transforms (null: none)
     Camera<R> cam;
+    __host__ __device__ Side<R> side() const { Side<R> s; s.tris = tris; s.xforms = xforms; return s; }
 };
 
 // `from`: id of the primitive the origin lies on (-1: none).  Only the fp32 modes read it, see prim_t.
@@ -375,7 +385,21 @@ template <typename R> __device__ inline bool volume_t(const Prim<R>& p, const Ra
     return true;
 }
 
-template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriShade<R>* aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
+// ray into an instance's frame: translate::intersect (transform.hpp:18-20), then rotatey::intersect (:83-92)
+template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const Ray<R>& r, Ray<R>& tr, Ray<R>& rr)
+{
+    tr = r;
+    if (x.flags & RT_PRIM_FLAG_TRANSLATE) tr.o = r.o - vec3<R>(x.t[0], x.t[1], x.t[2]);
+    rr = tr;
+    if (x.flags & RT_PRIM_FLAG_ROTATEY) {
+        rr.o.x = x.cs * tr.o.x - x.sn * tr.o.z;
+        rr.o.z = x.sn * tr.o.x + x.cs * tr.o.z;
+        rr.d.x = x.cs * tr.d.x - x.sn * tr.d.z;
+        rr.d.z = x.sn * tr.d.x + x.cs * tr.d.z;
+    }
+}
+
+template <typename R> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R a, b;
     if constexpr (sizeof(R) == sizeof(float)) {
@@ -396,6 +420,18 @@ template <typename R> __device__ inline bool prim_t(const Prim<R>& p, const TriS
     }
 }
 
+// the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
+template <typename R> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
+{
+    const int xi = p.xform();
+    if (xi >= 0) {
+        Ray<R> tr, rr;
+        xform_rays(aux.xforms[xi], r, tr, rr);
+        return prim_t_local(p, aux, rr, t_min, t_max, t, g);
+    }
+    return prim_t_local(p, aux, r, t_min, t_max, t, g);
+}
+
 // hit record (intersection.hpp:13-27)
 template <typename R> struct Hit {
     vec3<R> pos, normal;
@@ -413,8 +449,8 @@ template <typename R> __device__ inline void set_face_normal(Hit<R>& h, const Ra
 
 // Completes the record of a hit already known to lie at t on primitive p: the statements after the range test in
 // each intersect() (primitive.hpp:49-55, 123-129, 189-198; polygon.hpp:117-123; flip transform.hpp:134).
-template <typename R> __device__ inline void fill_record(const Prim<R>& p, const TriShade<R>* tris, const Ray<R>& r, R t,
-                                                         bool need_uv, Hit<R>& h)
+template <typename R> __device__ inline void fill_record_local(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t,
+                                                               bool need_uv, Hit<R>& h)
 {
     h.t = t;
     h.mat = p.mat;
@@ -474,6 +510,30 @@ template <typename R> __device__ inline void fill_record(const Prim<R>& p, const
     }
     }
     if (p.flags() & RT_PRIM_FLAG_FLIP) h.front = !h.front;
+}
+
+template <typename R> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
+{
+    const int xi = p.xform();
+    if (xi < 0) { fill_record_local(p, tris, r, t, need_uv, h); return; }
+    // member of an instance: the record is made in the instance's frame and comes back out through both wrappers' set_face_normal
+    const Xform<R>& x = tris.xforms[xi];
+    Ray<R> tr, rr;
+    xform_rays(x, r, tr, rr);
+    fill_record_local(p, tris, rr, t, need_uv, h);
+    if (x.flags & RT_PRIM_FLAG_ROTATEY) {                                   // transform.hpp:99-110
+        vec3<R> position = h.pos, normal = h.normal;
+        position.x = x.cs * h.pos.x + x.sn * h.pos.z;
+        position.z = -x.sn * h.pos.x + x.cs * h.pos.z;
+        normal.x = x.cs * h.normal.x + x.sn * h.normal.z;
+        normal.z = -x.sn * h.normal.x + x.cs * h.normal.z;
+        h.pos = position;
+        set_face_normal(h, rr, normal);
+    }
+    if (x.flags & RT_PRIM_FLAG_TRANSLATE) {                                 // transform.hpp:25-27
+        h.pos = h.pos + vec3<R>(x.t[0], x.t[1], x.t[2]);
+        set_face_normal(h, tr, h.normal);
+    }
 }
 
 template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h)
@@ -553,7 +613,7 @@ __device__ inline bool first_active_lane() { return (int) __lane_id() == __ffsll
 
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
 template <typename R, int kStats>   // 0: none, 1: count box/leaf tests, 2: counts + visit-order hash
-__device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, const TriShade<R>* __restrict__ aux,
+__device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, const Prim<R>* __restrict__ prims, Side<R> aux,
                                   const Ray<R>& r, R& t_hit, VisitStats* st, Rng* g = nullptr)
 {
     R closest = rt_inf<R>();
@@ -563,9 +623,12 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
     while (i < n_ops) {
         const Op<R> op = ops[i];
         if (kStats == 2) st->hash = (st->hash ^ (uint64_t) (uint32_t) i) * 0x100000001B3ULL;
-        if (op.prim < 0) {
+        if (op.prim < 0) {                                                  // -1: world space; -2 - x: a node of instance x, box in its frame
             if (kStats) st->n_box++;
-            i = box_hit(op, r, t_min, closest) ? i + 1 : op.skip;
+            bool inside;
+            if (op.prim == -1) inside = box_hit(op, r, t_min, closest);
+            else { Ray<R> tr, rr; xform_rays(aux.xforms[-2 - op.prim], r, tr, rr); inside = box_hit(op, rr, t_min, closest); }
+            i = inside ? i + 1 : op.skip;
         }
         else {
             if (kStats) st->n_leaf++;
@@ -597,7 +660,7 @@ __device__ inline void slab2(const float* b, const vec3<float>& o, const vec3<fl
 }
 
 template <int kStats>
-__device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, const TriShade<float>* __restrict__ aux,
+__device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Prim<float>* __restrict__ prims, Side<float> aux,
                                       const Ray<float>& r, float& t_hit, uint32_t* stack, VisitStats* st, Rng* g = nullptr)
 {
     const float t_min = consts<float>::tmin;
@@ -1015,12 +1078,12 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
             if (kCount && first_active_lane()) vs.w_bounce++;
             R t;
             int prim;
-            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.tris, ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs, &g);
-            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, sc.tris, ray, t, &vs, &g);
+            if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.side(), ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs, &g);
+            else prim = closest_hit<R, kCount ? 1 : 0>(ops, sc.n_ops, prims, sc.side(), ray, t, &vs, &g);
             bool done = true;
             if (prim >= 0) {
                 Hit<R> h;
-                fill_record(kTrav == 2 ? sc.fprims[prim] : prims[prim], sc.tris, ray, t, sc.need_uv != 0, h);
+                fill_record(kTrav == 2 ? sc.fprims[prim] : prims[prim], sc.side(), ray, t, sc.need_uv != 0, h);
                 const Mat<R>& m = sc.mats[h.mat];
                 const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
                 vec3<R> emission = mat_emit(m, h, texc);
@@ -1113,13 +1176,13 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
     r.time = R(p[6]);
     VisitStats st; st.n_box = 0; st.n_leaf = 0; st.hash = 0xcbf29ce484222325ULL; st.w_node = st.w_leaf = st.w_bounce = 0;
     R t;
-    int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, sc.tris, r, t, &st);
+    int hit = closest_hit<R, 2>(sc.ops, sc.n_ops, sc.prims, sc.side(), r, t, &st);
     prim[idx] = hit;
     t_out[idx] = hit >= 0 ? (double) t : 0.0;
     int f = -1;
     if (hit >= 0) {
         Hit<R> h;
-        fill_record(sc.prims[hit], sc.tris, r, t, false, h);
+        fill_record(sc.prims[hit], sc.side(), r, t, false, h);
         f = h.front ? 1 : 0;
     }
     front[idx] = f;
@@ -1140,7 +1203,7 @@ __global__ void __launch_bounds__(256) first_hit_fast_kernel(Scene<float> sc, co
     r.d = vec3<float>((float) p[3], (float) p[4], (float) p[5]);
     r.time = (float) p[6];
     float t;
-    int hit = closest_hit_bvh<0>(sc.bnodes, sc.fprims, sc.tris, r, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, nullptr);
+    int hit = closest_hit_bvh<0>(sc.bnodes, sc.fprims, sc.side(), r, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, nullptr);
     prim[idx] = hit >= 0 ? sc.fprims[hit].id : -1;
     t_out[idx] = hit >= 0 ? t : 0.0f;
 }

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, RT_WF_EXTEND_WAVES) wf_extend_kernel(Scen
                 float t;
                 if (kCount && first_active_lane()) vs.w_leaf++;
                 if (kCount) vs.n_leaf++;
-                if (prim_t(fprims[first + k], sc.tris, ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
+                if (prim_t(fprims[first + k], sc.side(), ray, t_min, tv.closest, t)) { tv.closest = t; tv.hit = first + k; }
             }
             tv.cur = (int32_t) pop(tv.sp); tv.sp--;
         }
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) wf_shade_kernel(Scene<floa
         done = true;
         if (prim >= 0) {
             Hit<float> h;
-            fill_record(sc.fprims[prim], sc.tris, ray, ht.x, sc.need_uv != 0, h);
+            fill_record(sc.fprims[prim], sc.side(), ray, ht.x, sc.need_uv != 0, h);
             const Mat<float>& m = sc.mats[h.mat];
             const vec3<float> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<float>();
                 vec3<float> emission = mat_emit(m, h, texc);

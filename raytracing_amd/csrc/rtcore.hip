@@ -109,6 +109,20 @@ int validate(const rt_scene_desc* d)
         if (d->prim_kind[i] == RT_PRIM_VOLUME && (d->mat_kind[d->prim_mat[i]] != RT_MAT_FOG || d->prim_flags[i] != 0))
             return fail(RT_EINVAL, "a volume takes a fog material and no wrapper flags (primitive.hpp:332-344)");
     }
+    if (d->n_xforms < 0 || d->n_xforms > 65534 || (d->n_xforms && (!d->xform_data || !d->prim_xform || (d->n_nodes && !d->node_xform))))
+        return fail(RT_EINVAL, "instance transforms: 0..65534 of them, with xform_data, node_xform and prim_xform present");
+    for (int i = 0; i < d->n_xforms; i++) {
+        const int fl = (int) d->xform_data[(size_t) i * RT_XFORM_STRIDE + 5];
+        if (fl == 0 || (fl & ~(RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE))) return fail(RT_EINVAL, "instance transform: wrappers must be ROTATEY and / or TRANSLATE");
+    }
+    if (d->n_xforms) {
+        for (int i = 0; i < d->n_nodes; i++) if (d->node_xform[i] < -1 || d->node_xform[i] >= d->n_xforms) return fail(RT_EINVAL, "node_xform out of range");
+        for (int i = 0; i < d->n_prims; i++) {
+            if (d->prim_xform[i] < -1 || d->prim_xform[i] >= d->n_xforms) return fail(RT_EINVAL, "prim_xform out of range");
+            if (d->prim_xform[i] >= 0 && (d->prim_kind[i] == RT_PRIM_BOX || d->prim_kind[i] == RT_PRIM_VOLUME))
+                return fail(RT_EINVAL, "a box carries its wrappers in its own record, a volume takes none: prim_xform must be -1");
+        }
+    }
     for (int i = 0; i < d->n_lights; i++)
         if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown light kind (a volume cannot be a light)");
     for (int i = 0; i < d->n_mats; i++) {
@@ -151,7 +165,7 @@ int linearize(const rt_scene_desc* d, Flat& f)
             }
             if (fr.stage == 0) {
                 fr.op = (int) f.op_prim.size();
-                f.op_prim.push_back(-1); f.op_skip.push_back(0);
+                f.op_prim.push_back(d->n_xforms && d->node_xform[fr.code] >= 0 ? -2 - d->node_xform[fr.code] : -1); f.op_skip.push_back(0);   // see rt_device.h closest_hit
                 for (int k = 0; k < 6; k++) f.op_box.push_back(d->node_bbox[(size_t) fr.code * 6 + k]);
                 fr.stage = 1;
                 int32_t child = d->node_child[(size_t) fr.code * 2];
@@ -172,10 +186,10 @@ int linearize(const rt_scene_desc* d, Flat& f)
     return RT_OK;
 }
 
-template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g, int id)
+template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int kind, int flags, int mat, const double* g, int id, int xform = -1)
 {
     std::memset(&p, 0, sizeof p);
-    p.kf = kind | (flags << 8); p.mat = mat; p.id = id;
+    p.kf = (int32_t) ((uint32_t) kind | ((uint32_t) (flags & 0xff) << 8) | ((uint32_t) (xform + 1) << 16)); p.mat = mat; p.id = id;
     int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_VOLUME ? 5 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : kind == RT_PRIM_BOX ? 8 : 5;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
     if (tri) {
@@ -232,6 +246,19 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
         b.grow(lo); b.grow(hi);
         break;
     }
+    }
+    if (d->n_xforms && d->prim_xform[i] >= 0) {   // member of an instance: the eight corners of its own box, out of the instance's frame
+        const double* x = d->xform_data + (size_t) d->prim_xform[i] * RT_XFORM_STRIDE;
+        const int fl = (int) x[5];
+        const double sn = (fl & RT_PRIM_FLAG_ROTATEY) ? x[0] : 0.0, cs = (fl & RT_PRIM_FLAG_ROTATEY) ? x[1] : 1.0;
+        rtb::Box w;
+        for (int c = 0; c < 8; c++) {
+            const double px = (c & 1) ? b.hi[0] : b.lo[0], py = (c & 2) ? b.hi[1] : b.lo[1], pz = (c & 4) ? b.hi[2] : b.lo[2];
+            double p[3] = { cs * px + sn * pz, py, -sn * px + cs * pz };
+            if (fl & RT_PRIM_FLAG_TRANSLATE) for (int k = 0; k < 3; k++) p[k] += x[2 + k];
+            w.grow(p);
+        }
+        b = w;
     }
     for (int k = 0; k < 3; k++) {   // pad flat boxes (rects, axis-aligned triangles) like the reference pads them (primitive.hpp:203, polygon.hpp:128)
         double pad = 1e-4 + 1e-6 * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
@@ -323,7 +350,8 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     std::vector<rt::Prim<R>> prims(d->n_prims);
     std::vector<rt::TriShade<R>> tris(has_tri ? d->n_prims : 0);
     for (int i = 0; i < d->n_prims; i++)
-        fill_prim<R>(prims[i], has_tri ? &tris[i] : nullptr, d->prim_kind[i], d->prim_flags[i], d->prim_mat[i], d->prim_data + (size_t) i * RT_PRIM_STRIDE, i);
+        fill_prim<R>(prims[i], has_tri ? &tris[i] : nullptr, d->prim_kind[i], d->prim_flags[i], d->prim_mat[i], d->prim_data + (size_t) i * RT_PRIM_STRIDE, i,
+                     d->n_xforms ? d->prim_xform[i] : -1);
     std::vector<rt::Prim<R>> lights(d->n_lights);
     std::vector<rt::TriShade<R>> ltris(light_tri ? d->n_lights : 0);
     for (int i = 0; i < d->n_lights; i++)
@@ -346,6 +374,13 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         else if (t.kind == RT_TEX_CHECKER) { t.a = (int) td[0]; t.b = (int) td[1]; }
         else { t.a = (int) td[0]; t.b = (int) td[1]; t.ch = (int) td[2]; t.color_based = td[3] != 0; t.offset = (uint32_t) td[4]; need_uv = true; }
     }
+    std::vector<rt::Xform<R>> xforms(d->n_xforms);
+    for (int i = 0; i < d->n_xforms; i++) {
+        const double* x = d->xform_data + (size_t) i * RT_XFORM_STRIDE;
+        xforms[i].flags = (int32_t) x[5];
+        xforms[i].sn = (xforms[i].flags & RT_PRIM_FLAG_ROTATEY) ? (R) x[0] : R(0); xforms[i].cs = (xforms[i].flags & RT_PRIM_FLAG_ROTATEY) ? (R) x[1] : R(1);
+        for (int k = 0; k < 3; k++) xforms[i].t[k] = (xforms[i].flags & RT_PRIM_FLAG_TRANSLATE) ? (R) x[2 + k] : R(0);
+    }
     std::vector<uint8_t> pixels(d->tex_pixels ? d->tex_pixels : nullptr, d->tex_pixels ? d->tex_pixels + d->n_pixel_bytes : nullptr);
 
     rt::Scene<R>& v = out.view;
@@ -357,6 +392,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     if ((rc = upload(out.owned, texs, &v.texs))) return rc;
     if ((rc = upload(out.owned, pixels, &v.pixels))) return rc;
     if ((rc = upload(out.owned, lights, &v.lights))) return rc;
+    if (d->n_xforms) { if ((rc = upload(out.owned, xforms, &v.xforms))) return rc; } else v.xforms = nullptr;
     if (light_tri) { if ((rc = upload(out.owned, ltris, &v.light_tris))) return rc; } else v.light_tris = nullptr;
     v.n_ops = n_ops; v.n_prims = d->n_prims; v.n_lights = d->n_lights; v.need_uv = need_uv;
     const double* c = d->camera;
@@ -624,23 +660,26 @@ int rt_buffer_upload(void* dev_dst, const void* host_src, size_t bytes) { HIP_TR
 // ---- binary scene cache: header, then the arrays in declaration order, each padded to 8 bytes
 namespace {
 struct CacheHeader {
-    char magic[8];                      // "RTSCENE1"
-    int32_t n_nodes, n_roots, n_prims, n_mats, n_tex, n_lights;
+    char magic[8];                      // "RTSCENE2"
+    int32_t n_nodes, n_roots, n_prims, n_mats, n_tex, n_lights, n_xforms, pad;
     uint64_t n_pixel_bytes;
     double camera[24];
 };
 struct CacheArray { const void* src; size_t bytes; };
 size_t pad8(size_t n) { return (n + 7) & ~(size_t) 7; }
-void cache_arrays(const rt_scene_desc* d, CacheArray a[17])
+enum { kCacheArrays = 20 };
+void cache_arrays(const rt_scene_desc* d, CacheArray a[kCacheArrays])
 {
     const size_t nn = (size_t) d->n_nodes, np = (size_t) d->n_prims, nm = (size_t) d->n_mats, nt = (size_t) d->n_tex, nl = (size_t) d->n_lights;
-    const CacheArray v[17] = {
+    const size_t nx = (size_t) d->n_xforms;
+    const CacheArray v[kCacheArrays] = {
         { d->node_bbox, nn * 6 * 8 }, { d->node_child, nn * 2 * 4 }, { d->roots, (size_t) d->n_roots * 4 },
         { d->prim_kind, np * 4 }, { d->prim_flags, np * 4 }, { d->prim_mat, np * 4 }, { d->prim_data, np * RT_PRIM_STRIDE * 8 },
         { d->mat_kind, nm * 4 }, { d->mat_tex, nm * 4 }, { d->mat_data, nm * RT_MAT_STRIDE * 8 },
         { d->tex_kind, nt * 4 }, { d->tex_data, nt * RT_TEX_STRIDE * 8 }, { d->tex_pixels, d->n_pixel_bytes },
-        { d->light_kind, nl * 4 }, { d->light_flags, nl * 4 }, { d->light_mat, nl * 4 }, { d->light_data, nl * RT_PRIM_STRIDE * 8 } };
-    for (int i = 0; i < 17; i++) a[i] = v[i];
+        { d->light_kind, nl * 4 }, { d->light_flags, nl * 4 }, { d->light_mat, nl * 4 }, { d->light_data, nl * RT_PRIM_STRIDE * 8 },
+        { d->xform_data, nx * RT_XFORM_STRIDE * 8 }, { d->node_xform, nx ? nn * 4 : 0 }, { d->prim_xform, nx ? np * 4 : 0 } };
+    for (int i = 0; i < kCacheArrays; i++) a[i] = v[i];
 }
 struct CheckpointHeader { char magic[8]; int32_t width, height, spp_done, is_fp64; uint64_t seed; };   // "RTCKPT01"
 }  // namespace
@@ -653,15 +692,15 @@ int rt_scene_desc_save(const rt_scene_desc* d, const char* path)
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(RT_EINVAL, std::string("cannot write ") + path);
     CacheHeader h{};
-    std::memcpy(h.magic, "RTSCENE1", 8);
-    h.n_nodes = d->n_nodes; h.n_roots = d->n_roots; h.n_prims = d->n_prims; h.n_mats = d->n_mats; h.n_tex = d->n_tex; h.n_lights = d->n_lights;
+    std::memcpy(h.magic, "RTSCENE2", 8);
+    h.n_nodes = d->n_nodes; h.n_roots = d->n_roots; h.n_prims = d->n_prims; h.n_mats = d->n_mats; h.n_tex = d->n_tex; h.n_lights = d->n_lights; h.n_xforms = d->n_xforms;
     h.n_pixel_bytes = d->n_pixel_bytes;
     std::memcpy(h.camera, d->camera, sizeof h.camera);
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
-    CacheArray a[17];
+    CacheArray a[kCacheArrays];
     cache_arrays(d, a);
     const char zeros[8] = { 0 };
-    for (int i = 0; i < 17 && ok; i++) {
+    for (int i = 0; i < kCacheArrays && ok; i++) {
         if (a[i].bytes && a[i].src) ok = std::fwrite(a[i].src, 1, a[i].bytes, f) == a[i].bytes;
         else if (a[i].bytes) { std::fclose(f); return fail(RT_EINVAL, "a required array of the scene description is NULL"); }
         const size_t padding = pad8(a[i].bytes) - a[i].bytes;
@@ -678,15 +717,15 @@ int rt_scene_desc_load(const char* path, rt_scene_desc** out)
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(RT_EINVAL, std::string("cannot read ") + path);
     CacheHeader h{};
-    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "RTSCENE1", 8) != 0 || h.n_nodes < 0 || h.n_roots <= 0 || h.n_prims <= 0 ||
-        h.n_mats <= 0 || h.n_tex < 0 || h.n_lights < 0) { std::fclose(f); return fail(RT_EINVAL, std::string(path) + " is not a scene cache"); }
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "RTSCENE2", 8) != 0 || h.n_nodes < 0 || h.n_roots <= 0 || h.n_prims <= 0 ||
+        h.n_mats <= 0 || h.n_tex < 0 || h.n_lights < 0 || h.n_xforms < 0 || h.n_xforms > 65534) { std::fclose(f); return fail(RT_EINVAL, std::string(path) + " is not a scene cache"); }
     rt_scene_desc tmp{};
-    tmp.n_nodes = h.n_nodes; tmp.n_roots = h.n_roots; tmp.n_prims = h.n_prims; tmp.n_mats = h.n_mats; tmp.n_tex = h.n_tex; tmp.n_lights = h.n_lights;
+    tmp.n_nodes = h.n_nodes; tmp.n_roots = h.n_roots; tmp.n_prims = h.n_prims; tmp.n_mats = h.n_mats; tmp.n_tex = h.n_tex; tmp.n_lights = h.n_lights; tmp.n_xforms = h.n_xforms;
     tmp.n_pixel_bytes = (size_t) h.n_pixel_bytes;
-    CacheArray a[17];
+    CacheArray a[kCacheArrays];
     cache_arrays(&tmp, a);
     size_t total = pad8(sizeof(rt_scene_desc));
-    for (int i = 0; i < 17; i++) total += pad8(a[i].bytes);
+    for (int i = 0; i < kCacheArrays; i++) total += pad8(a[i].bytes);
     // the file must hold exactly what the header promises (a truncated or foreign file must not drive a huge allocation)
     std::fseek(f, 0, SEEK_END);
     const long size = std::ftell(f);
@@ -698,9 +737,9 @@ int rt_scene_desc_load(const char* path, rt_scene_desc** out)
     *d = tmp;
     std::memcpy(d->camera, h.camera, sizeof h.camera);
     char* p = block + pad8(sizeof(rt_scene_desc));
-    const void* ptrs[17];
+    const void* ptrs[kCacheArrays];
     bool ok = true;
-    for (int i = 0; i < 17 && ok; i++) {
+    for (int i = 0; i < kCacheArrays && ok; i++) {
         ptrs[i] = a[i].bytes ? p : nullptr;
         const size_t n = pad8(a[i].bytes);
         if (n) ok = std::fread(p, 1, n, f) == n;
@@ -713,6 +752,7 @@ int rt_scene_desc_load(const char* path, rt_scene_desc** out)
     d->mat_kind = (const int32_t*) ptrs[7]; d->mat_tex = (const int32_t*) ptrs[8]; d->mat_data = (const double*) ptrs[9];
     d->tex_kind = (const int32_t*) ptrs[10]; d->tex_data = (const double*) ptrs[11]; d->tex_pixels = (const uint8_t*) ptrs[12];
     d->light_kind = (const int32_t*) ptrs[13]; d->light_flags = (const int32_t*) ptrs[14]; d->light_mat = (const int32_t*) ptrs[15]; d->light_data = (const double*) ptrs[16];
+    d->xform_data = (const double*) ptrs[17]; d->node_xform = (const int32_t*) ptrs[18]; d->prim_xform = (const int32_t*) ptrs[19];
     const int rc = validate(d);                 // a cache is input like any other: index ranges are checked before anything walks it
     if (rc) { std::free(block); return rc; }
     *out = d;

@@ -115,5 +115,7 @@ class HostScene:
             light_mat=arr(d.light_mat, d.n_lights, np.int32),
             light_data=arr(d.light_data, d.n_lights * PRIM_STRIDE, np.float64).reshape(-1, PRIM_STRIDE),
             camera=np.array(list(d.camera)), n_pixel_bytes=int(d.n_pixel_bytes), width=self.width, height=self.height,
+            xform_data=arr(d.xform_data, d.n_xforms * 6, np.float64).reshape(-1, 6),
+            node_xform=arr(d.node_xform, d.n_nodes if d.n_xforms else 0, np.int32), prim_xform=arr(d.prim_xform, d.n_prims if d.n_xforms else 0, np.int32),
         )
         return out

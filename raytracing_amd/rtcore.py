@@ -35,6 +35,7 @@ class SceneDesc(C.Structure):
         ("n_lights", C.c_int32), ("light_kind", C.POINTER(C.c_int32)), ("light_flags", C.POINTER(C.c_int32)), ("light_mat", C.POINTER(C.c_int32)),
         ("light_data", C.POINTER(C.c_double)),
         ("camera", C.c_double * 24),
+        ("n_xforms", C.c_int32), ("xform_data", C.POINTER(C.c_double)), ("node_xform", C.POINTER(C.c_int32)), ("prim_xform", C.POINTER(C.c_int32)),
     ]
 
 
@@ -126,6 +127,9 @@ def make_desc(d):
                                      "light_kind", "light_flags", "light_mat")})
     keep["tex_pixels"] = np.ascontiguousarray(d.get("tex_pixels", np.zeros(1, np.uint8)), dtype=np.uint8)
     s = SceneDesc()
+    if "xform_data" in d and len(np.asarray(d["xform_data"]).ravel()):      # instances (optional)
+        keep["xform_data"] = f64("xform_data"); keep["node_xform"] = i32("node_xform"); keep["prim_xform"] = i32("prim_xform")
+        s.n_xforms = keep["xform_data"].size // 6
     s.n_nodes = len(keep["node_child"].reshape(-1, 2))
     s.n_roots = keep["roots"].size
     s.n_prims = keep["prim_kind"].size
@@ -215,7 +219,9 @@ def desc_to_arrays(desc):
         tex_pixels=arr(d.tex_pixels, d.n_pixel_bytes, np.uint8), n_pixel_bytes=int(d.n_pixel_bytes),
         light_kind=arr(d.light_kind, d.n_lights, np.int32), light_flags=arr(d.light_flags, d.n_lights, np.int32),
         light_mat=arr(d.light_mat, d.n_lights, np.int32), light_data=arr(d.light_data, d.n_lights * PRIM_STRIDE, np.float64).reshape(-1, PRIM_STRIDE),
-        camera=np.array(list(d.camera), np.float64))
+        camera=np.array(list(d.camera), np.float64),
+        xform_data=arr(d.xform_data, d.n_xforms * 6, np.float64).reshape(-1, 6),
+        node_xform=arr(d.node_xform, d.n_nodes if d.n_xforms else 0, np.int32), prim_xform=arr(d.prim_xform, d.n_prims if d.n_xforms else 0, np.int32))
 
 
 def save_scene_cache(desc_arrays, path):

@@ -191,6 +191,10 @@ class Scene:
                          _p(d["camera"], D))
         d["n_pixel_bytes"] = nb
         d["width"], d["height"] = self.width, self.height
+        nx = int(c[7])
+        if nx:     # instances: translate / rotatey around a nested bvh
+            d.update(xform_data=np.zeros((nx, 6)), node_xform=np.zeros(nn, np.int32), prim_xform=np.zeros(npr, np.int32))
+            lib().orc_export_instances(self.h, _p(d["xform_data"], D), _p(d["node_xform"], I), _p(d["prim_xform"], I))
         return d
 
     # ---- hot path
@@ -417,6 +421,8 @@ def scene_from_arrays(d, seed=1):
             s.mat_fog(t)
         else:
             s.mat_phong(m[1:4], m[4:7], m[7:10], m[10:13], m[13], m[14], t)
+    if len(np.asarray(d.get("xform_data", [])).ravel()):
+        raise NotImplementedError("scene_from_arrays: instanced sub-trees are not rebuilt from flattened arrays")
     I, D = C.c_int32, C.c_double
     for pre, to_lights in (("prim", 0), ("light", 1)):
         kind = np.ascontiguousarray(d[pre + "_kind"], np.int32)
