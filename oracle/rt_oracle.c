@@ -1382,7 +1382,7 @@ static int export_node(const orc_obj* o, exp_ctx* c)
     if (c->bbox) { put3(c->bbox + 6 * idx, o->box.mn); put3(c->bbox + 6 * idx + 3, o->box.mx); }
     if (c->node_xform) c->node_xform[idx] = c->cur;
     int l = export_node(o->l, c);
-    int r = (o->r == o->l && o->l->kind != O_BVH && o->l->kind != O_TRANSLATE && o->l->kind != O_ROTATEY) ? l : export_node(o->r, c);
+    int r = o->r == o->l ? l : export_node(o->r, c);                  /* span 1 (bvh.hpp:31-34): the same child twice */
     if (c->child) { c->child[2 * idx] = l; c->child[2 * idx + 1] = r; }
     return idx;
 }

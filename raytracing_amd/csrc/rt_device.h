@@ -421,10 +421,11 @@ template <typename R> __device__ inline bool prim_t_local(const Prim<R>& p, Side
 }
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
-template <typename R> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
+// (kInst = false: the caller knows the scene has no instances -- the fast kernel is compiled both ways, the check costs it ~10 %)
+template <typename R, bool kInst = true> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
 {
-    const int xi = p.xform();
-    if (xi >= 0) {
+    const int xi = kInst ? p.xform() : -1;
+    if (kInst && xi >= 0) {
         Ray<R> tr, rr;
         xform_rays(aux.xforms[xi], r, tr, rr);
         return prim_t_local(p, aux, rr, t_min, t_max, t, g);
@@ -512,10 +513,10 @@ template <typename R> __device__ inline void fill_record_local(const Prim<R>& p,
     if (p.flags() & RT_PRIM_FLAG_FLIP) h.front = !h.front;
 }
 
-template <typename R> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
+template <typename R, bool kInst = true> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
 {
-    const int xi = p.xform();
-    if (xi < 0) { fill_record_local(p, tris, r, t, need_uv, h); return; }
+    const int xi = kInst ? p.xform() : -1;
+    if (!kInst || xi < 0) { fill_record_local(p, tris, r, t, need_uv, h); return; }
     // member of an instance: the record is made in the instance's frame and comes back out through both wrappers' set_face_normal
     const Xform<R>& x = tris.xforms[xi];
     Ray<R> tr, rr;
@@ -963,6 +964,7 @@ struct RenderArgs {
     // regenerate when at least regen_min lanes have no path (or none has one)
     uint32_t trav_keep, node_keep, regen_min;
     uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
+    uint32_t instances;                        // the scene has instance transforms (Scene::xforms)
 };
 
 // ------------------------------------------------------------------ render kernel

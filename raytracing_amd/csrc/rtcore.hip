@@ -152,7 +152,8 @@ int linearize(const rt_scene_desc* d, Flat& f)
 {
     struct Frame { int32_t code; int stage; int op; };
     std::vector<Frame> stack;
-    size_t guard = (size_t) d->n_nodes * 3 + (size_t) d->n_roots + 16;
+    // a span-1 node names the same child twice (bvh.hpp:31-34) and the program repeats that sub-tree, as the reference walks it twice
+    size_t guard = (size_t) d->n_nodes * 16 + (size_t) d->n_roots + 16;
     for (int r = 0; r < d->n_roots; r++) {
         stack.push_back({ d->roots[r], 0, -1 });
         while (!stack.empty()) {
@@ -266,18 +267,26 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
     }
 }
 
-template <typename R> int build_fast_tree(const rt_scene_desc*, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out)
+template <typename R> int build_fast_tree(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out)
 {
     out.view.bnodes = nullptr; out.view.qnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
     return RT_OK;
 }
-template <> int build_fast_tree<float>(const rt_scene_desc* d, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out)
+template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out)
 {
     std::vector<rtb::Item> items(d->n_prims);
     for (int i = 0; i < d->n_prims; i++) {
         prim_bounds(d, i, items[i].box);
         for (int k = 0; k < 3; k++) items[i].c[k] = 0.5 * (items[i].box.lo[k] + items[i].box.hi[k]);
         items[i].id = i;
+    }
+    // A volume draws its free-flight distance at every test.  Where the reference tree names a volume more than once (both
+    // children of a span-1 node, bvh.hpp:31-34: all_feature_test() under scene::build_bvh) the reference tests it that often per
+    // ray, and so must this tree, or the medium would scatter less: such a volume enters the builder once per occurrence.
+    {
+        std::vector<int> seen(d->n_prims, 0);
+        for (int32_t p : f.op_prim)
+            if (p >= 0 && d->prim_kind[p] == RT_PRIM_VOLUME && seen[p]++ > 0) items.push_back(items[p]);
     }
     int leaf_max = 4; double c_prim = 1.5;
     if (const char* e = std::getenv("RT_BVH_LEAF")) leaf_max = std::atoi(e);
@@ -399,7 +408,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };
     v.cam.pos = v3(0); v.cam.left_bottom = v3(3); v.cam.horizontal = v3(6); v.cam.vertical = v3(9); v.cam.u = v3(12); v.cam.v = v3(15);
     v.cam.lens_radius = (R) c[21]; v.cam.s0 = (R) c[22]; v.cam.s1 = (R) c[23];
-    if ((rc = build_fast_tree(d, prims, out))) return rc;
+    if ((rc = build_fast_tree(d, f, prims, out))) return rc;
     out.ops_bytes = (uint32_t) (((size_t) n_ops * sizeof(rt::Op<R>) + 15) / 16 * 16);
     out.prims_bytes = (uint32_t) (((size_t) d->n_prims * sizeof(rt::Prim<R>) + 15) / 16 * 16);
     return RT_OK;
@@ -538,7 +547,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
-    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised;
+    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.instances = s->d32.view.xforms != nullptr;
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
         if (s->has_volume) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT: the extend kernel has no random stream, which a volume's intersection test draws from");
         int rc = wf_prepare(s);

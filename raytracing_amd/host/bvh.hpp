@@ -80,8 +80,17 @@ private:
 };
 
 // ---- flattener traversal (needs the complete bvh / group types)
+// the bvh under o's translate / rotatey wrappers, or null when o is not an instance of a sub-tree
+static inline const bvh* instanced_bvh(const object* o, flat_xform& x)
+{
+    const object* in = o;
+    while (const object* next = in->peel_transform(x)) in = next;
+    return in != o ? dynamic_cast<const bvh*>(in) : nullptr;
+}
+
 inline void flattener::collect(const object* o)
 {
+    { flat_xform x; if (const bvh* nested = instanced_bvh(o, x)) { collect(nested); return; } }
     if (const bvh* b = dynamic_cast<const bvh*>(o)) { collect(b->left); if (b->right != b->left) collect(b->right); return; }
     if (const group* g = dynamic_cast<const group*>(o)) { for (int i = 0; i < g->size(); i++) collect(g->content()[i]); return; }
     leaves.push_back(std::make_pair(o->serial, o));
@@ -89,13 +98,24 @@ inline void flattener::collect(const object* o)
 
 inline int32_t flattener::emit(const object* o)
 {
+    {
+        flat_xform x;
+        if (const bvh* nested = instanced_bvh(o, x)) {       // translate(rotatey(bvh)): the sub-tree stays in its own frame
+            if (cur_xform >= 0) throw std::runtime_error("flatten: an instance inside an instance is not supported");
+            cur_xform = xform_id(x);
+            int32_t code = emit(nested);
+            cur_xform = -1;
+            return code;
+        }
+    }
     if (const bvh* b = dynamic_cast<const bvh*>(o)) {
         int32_t idx = (int32_t) (out.node_child.size() / 2);
         out.node_child.push_back(0); out.node_child.push_back(0);
+        out.node_xform.push_back(cur_xform);
         for (int k = 0; k < 3; k++) out.node_bbox.push_back(b->bbox.min()[k]);
         for (int k = 0; k < 3; k++) out.node_bbox.push_back(b->bbox.max()[k]);
         int32_t l = emit(b->left);
-        int32_t r = emit(b->right);
+        int32_t r = b->right == b->left ? l : emit(b->right);      // span 1 (reference bvh.hpp:31-34): the same child twice
         out.node_child[(size_t) idx * 2] = l;
         out.node_child[(size_t) idx * 2 + 1] = r;
         return idx;
@@ -104,5 +124,10 @@ inline int32_t flattener::emit(const object* o)
     if (!o->leaf_record(leaf)) throw std::runtime_error("flatten: object type is not supported inside a bvh (nested group / unknown class)");
     int id = prim_ids.at(o);
     store_prim(id, leaf);
+    if (leaf.xform.flags) {
+        if (cur_xform >= 0) throw std::runtime_error("flatten: a wrapped primitive inside an instance is not supported");
+        out.prim_xform[id] = xform_id(leaf.xform);
+    }
+    else out.prim_xform[id] = cur_xform;
     return ~id;
 }

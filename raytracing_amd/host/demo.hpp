@@ -70,6 +70,52 @@ inline group deep_bounce_scene()
     return group(new bvh(grp, 0, 1));
 }
 
+// reference: src/cpp/demo.hpp:94-143, statement for statement (the image path of :132 does not exist anywhere: the texture
+// fails to load and is cyan, texture.hpp:97-99)
+inline group all_feature_test()
+{
+    group grp;
+    group ground_boxes;
+    material* white_mat = new lambertian(vec3d(0.73, 0.73, 0.73));
+    material* ground_mat = new lambertian(vec3d(0.48, 0.83, 0.53));
+    material* area_light = new emissive(vec3d(7, 7, 7));
+    for (int i = 0; i < 20; i++) {
+        for (int j = 0; j < 20; j++) {
+            double w = 100;
+            double x0 = -1000 + i * w;
+            double z0 = -1000 + j * w;
+            double y0 = 0;
+            double x1 = x0 + w;
+            double z1 = z0 + w;
+            double y1 = random_double(1, 101);
+            ground_boxes.add(new box(vec3d(x0, y0, z0), vec3d(x1, y1, z1), ground_mat));
+        }
+    }
+    grp.add(ground_boxes);
+    grp.add(new planexz(123, 423, 147, 412, 554, area_light));
+    vec3d center_start = vec3d(400, 400, 200);
+    vec3d center_end = center_start + vec3d(100, 0, 0);
+    material* motion_ball_mat = new lambertian(vec3d(0.7, 0.3, 0.1));
+    grp.add(new msphere(center_start, center_end, 0, 1, 50, motion_ball_mat));
+    grp.add(new sphere(vec3d(260, 150, 45), 50, new dielectric(1.5)));
+    grp.add(new sphere(vec3d(0, 150, 145), 50, new metal(vec3d(0.8, 0.8, 0.9), 1)));
+    object* background = new sphere(vec3d(0, 0, 0), 5000, new dielectric(1.5));
+    grp.add(new volume(background, 0.0002, vec3d(1, 1, 1)));
+    background = new sphere(vec3d(360, 150, 145), 70, new dielectric(1.5));
+    grp.add(background);
+    grp.add(new volume(background, 0.2, vec3d(0.2, 0.4, 0.9)));
+    material* img_mat = new lambertian(new image("C:/Users/Cronix/Pictures/image.jpg"));
+    grp.add(new sphere(vec3d(400, 200, 400), 100, img_mat));
+    grp.add(new sphere(vec3d(220, 280, 300), 50, new metal(vec3d(1, 1, 1), 0)));
+    group vol_boxes;
+    for (int i = 0; i < 1000; i++) {
+        vol_boxes.add(new sphere(random_vector(0, 165), 10, white_mat));
+    }
+    grp.add(new translate(new rotatey(new bvh(vol_boxes), 15), vec3d(-100, 270, 395)));
+    bvh* bvh_grp = new bvh(grp, 0, 1);
+    return group(bvh_grp);
+}
+
 // the sphere-bounded media of all_feature_test() (reference: src/cpp/demo.hpp:117-134: haze in a radius-5000 sphere, a glass ball
 // filled with blue fog, moving / glass / fuzzy-metal / mirror spheres) over a ground rect, plus a free-standing smoke ball
 inline group smoke_scene()

@@ -22,8 +22,9 @@ class texture;
 inline uint64_t rt_next_serial() { static uint64_t counter = 0; return counter++; }
 
 struct flat_scene {
-    std::vector<double> node_bbox, prim_data, mat_data, tex_data, light_data;
+    std::vector<double> node_bbox, prim_data, mat_data, tex_data, light_data, xform_data;
     std::vector<int32_t> node_child, roots, prim_kind, prim_flags, prim_mat, mat_kind, mat_tex, tex_kind, light_kind, light_flags, light_mat;
+    std::vector<int32_t> node_xform, prim_xform;     // instances (rt_scene_desc): transform index per node / primitive, -1 = world space
     std::vector<uint8_t> tex_pixels;
     double camera[24] = { 0 };
 
@@ -41,8 +42,16 @@ struct flat_scene {
         d.n_lights = (int32_t) light_kind.size(); d.light_kind = light_kind.data(); d.light_flags = light_flags.data();
         d.light_mat = light_mat.data(); d.light_data = light_data.data();
         std::memcpy(d.camera, camera, sizeof camera);
+        d.n_xforms = (int32_t) (xform_data.size() / RT_XFORM_STRIDE);
+        if (d.n_xforms) { d.xform_data = xform_data.data(); d.node_xform = node_xform.data(); d.prim_xform = prim_xform.data(); }
         return d;
     }
+};
+
+// rotatey / translate wrappers peeled off an object (reference: src/cpp/transform.hpp:9-121); translate is the outer one
+struct flat_xform {
+    int flags = 0;                          // RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE
+    double sin_theta = 0, cos_theta = 1, target[3] = { 0, 0, 0 };
 };
 
 // one leaf as the flattener sees it
@@ -50,6 +59,7 @@ struct flat_leaf {
     int kind = 0, flags = 0;
     const material* mat = nullptr;
     double data[RT_PRIM_STRIDE] = { 0 };
+    flat_xform xform;                       // wrappers around a leaf that does not carry them in its own record (anything but a box)
 };
 
 class flattener {
@@ -70,7 +80,15 @@ public:
         for (size_t i = 0; i < leaves.size(); i++) prim_ids[leaves[i].second] = (int) i;
         out.prim_kind.resize(leaves.size()); out.prim_flags.resize(leaves.size()); out.prim_mat.resize(leaves.size());
         out.prim_data.assign(leaves.size() * RT_PRIM_STRIDE, 0.0);
+        out.prim_xform.assign(leaves.size(), -1);
     }
+    int xform_id(const flat_xform& x)
+    {
+        const double rec[RT_XFORM_STRIDE] = { x.sin_theta, x.cos_theta, x.target[0], x.target[1], x.target[2], (double) x.flags };
+        out.xform_data.insert(out.xform_data.end(), rec, rec + RT_XFORM_STRIDE);
+        return (int) (out.xform_data.size() / RT_XFORM_STRIDE) - 1;
+    }
+    int cur_xform = -1;                     // the instance being emitted
     void store_prim(int id, const flat_leaf& l)
     {
         out.prim_kind[id] = l.kind; out.prim_flags[id] = l.flags; out.prim_mat[id] = material_id(l.mat);

@@ -1,7 +1,9 @@
 // raytracing_amd/host/transform.hpp -- translate, rotatey, flip (reference: src/cpp/transform.hpp:9-149).
 // The wrappers describe geometry only; the ray transform and the wrappers' set_face_normal calls run in the HIP core
-// (csrc/rt_device.h box_t).  translate / rotatey are flattened around a `box` -- the combination cornell_box() builds
-// (demo.hpp:80-88): translate(rotatey(box)), rotatey(box), translate(box) or a bare box; other inner objects are refused.
+// (csrc/rt_device.h box_t / xform_rays).  Around a `box` -- what cornell_box() builds (demo.hpp:80-88) -- the wrappers
+// travel in the box's own record; around any other leaf or around a bvh -- all_feature_test()'s sphere cloud
+// (demo.hpp:136-140) -- they become an instance transform of the flattened scene.  Supported nesting, once:
+// translate(rotatey(x)), rotatey(x), translate(x).
 #pragma once
 
 #include <cmath>
@@ -21,11 +23,18 @@ public:
     bool leaf_record(flat_leaf& out) const override
     {
         if (!obj->leaf_record(out)) return false;
-        if (out.kind != RT_PRIM_BOX || (out.flags & RT_PRIM_FLAG_TRANSLATE))
-            throw std::runtime_error("flatten: translate is supported around box / rotatey(box) only");
+        if (out.kind != RT_PRIM_BOX) { peel_transform(out.xform); return true; }
+        if (out.flags & RT_PRIM_FLAG_TRANSLATE) throw std::runtime_error("flatten: translate(translate(.)) is not supported");
         out.flags |= RT_PRIM_FLAG_TRANSLATE;
         for (int k = 0; k < 3; k++) out.data[8 + k] = target[k];
         return true;
+    }
+    const object* peel_transform(flat_xform& x) const override
+    {
+        if (x.flags) throw std::runtime_error("flatten: translate is supported as the outermost wrapper only");
+        x.flags |= RT_PRIM_FLAG_TRANSLATE;
+        for (int k = 0; k < 3; k++) x.target[k] = target[k];
+        return obj;
     }
 private:
     object* obj;
@@ -61,11 +70,21 @@ public:
     bool leaf_record(flat_leaf& out) const override
     {
         if (!obj->leaf_record(out)) return false;
-        if (out.kind != RT_PRIM_BOX || (out.flags & (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE)))
-            throw std::runtime_error("flatten: rotatey is supported directly around a box only");
+        if (out.kind != RT_PRIM_BOX) {
+            if (out.xform.flags) throw std::runtime_error("flatten: rotatey is supported directly around the wrapped object only");
+            out.xform.flags |= RT_PRIM_FLAG_ROTATEY; out.xform.sin_theta = sin_theta; out.xform.cos_theta = cos_theta;
+            return true;
+        }
+        if (out.flags & (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE)) throw std::runtime_error("flatten: rotatey is supported directly around a box only");
         out.flags |= RT_PRIM_FLAG_ROTATEY;
         out.data[6] = sin_theta; out.data[7] = cos_theta;
         return true;
+    }
+    const object* peel_transform(flat_xform& x) const override
+    {
+        if (x.flags & RT_PRIM_FLAG_ROTATEY) throw std::runtime_error("flatten: rotatey(rotatey(.)) is not supported");
+        x.flags |= RT_PRIM_FLAG_ROTATEY; x.sin_theta = sin_theta; x.cos_theta = cos_theta;
+        return obj;
     }
 private:
     object* obj;

@@ -43,15 +43,23 @@ def desc_to_rows(d):
             r[3] = flags & 6      # rotatey / translate wrappers around the box
         mat_row(mat, r[30:])
 
-    def walk(code):
+    node_seen = {}
+    has_xf = len(np.asarray(d.get("xform_data", [])).ravel()) > 0
+
+    def walk(code, parent_xf=-1):
         idx = len(rows)
         r = np.zeros(ROW)
         rows.append(r)
         if code >= 0:
-            r[0] = 0; r[2] = idx
+            node_seen.setdefault(code, idx)       # a span-1 node names the same child twice: the harness dumps that sub-tree twice
+            r[0] = 0; r[2] = node_seen[code]
             r[4:10] = d["node_bbox"][code]
-            l = walk(int(d["node_child"][code][0]))
-            rr = walk(int(d["node_child"][code][1]))
+            xf = int(d["node_xform"][code]) if has_xf else -1
+            if xf >= 0 and parent_xf < 0:         # the root of an instanced sub-tree: the harness shows the wrappers on this entry
+                x = d["xform_data"][xf]
+                r[3] = x[5]; r[12:17] = x[0:5]
+            l = walk(int(d["node_child"][code][0]), xf)
+            rr = walk(int(d["node_child"][code][1]), xf)
             r[10] = l; r[11] = rr
         else:
             p = ~code
@@ -78,6 +86,7 @@ CASES = {
     "c0_seed7": ("c0", lambda gd, m: HostScene.random_spheres(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.c0(m["width"], m["height"], m["seed"])),
     "mixed": ("mixed", lambda gd, m: HostScene.mixed(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
     "cornell": ("cornell", lambda gd, m: HostScene.cornell(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
+    "features": ("features", lambda gd, m: HostScene.features(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.features(m["width"], m["height"], m["seed"])),
     "smoke": ("smoke", lambda gd, m: HostScene.smoke(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "obj": ("obj", lambda gd, m: HostScene.obj(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"]),
             lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
@@ -104,6 +113,11 @@ def test_host_scene_and_bvh_match_reference_fixture(golden_dir, name):
         assert np.array_equal(bits(d[k]), bits(od[k])), k
     for k in ("node_child", "roots", "prim_kind", "prim_flags", "light_kind", "light_flags"):
         assert np.array_equal(d[k], od[k]), k
+    if "xform_data" in od:                     # instances: same transforms, same membership
+        assert np.array_equal(bits(d["xform_data"]), bits(od["xform_data"]))
+        assert np.array_equal(d["node_xform"], od["node_xform"]) and np.array_equal(d["prim_xform"], od["prim_xform"])
+    else:
+        assert d["xform_data"].size == 0
     hs.free()
 
 
