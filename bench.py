@@ -96,9 +96,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path is the only path")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU (RCCL).  RT_BENCH_BACKEND=gloo is for rehearsing the N > 1 path on a box with fewer GPUs than ranks:
+    # ranks then share devices and the reduce goes through the host
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     w, h, spp = args.width, args.height, args.spp
     mode = {"fp32": R.MODE_FAST_FP32, "fp32ref": R.MODE_FP32_REFERENCE_TREE, "fp64": R.MODE_REFERENCE_FP64}[args.mode]
