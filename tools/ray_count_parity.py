@@ -23,7 +23,7 @@ args = ap.parse_args()
 w, h = args.width, args.height
 VARIANTS = (("fp64", R.MODE_REFERENCE_FP64, 0), ("fast", R.MODE_FAST_FP32, 0), ("fast_lanesync", R.MODE_FAST_FP32, R.FLAG_LEGACY_LOOP),
             ("reftree", R.MODE_FP32_REFERENCE_TREE, 0), ("fast_wavefront", R.MODE_FAST_FP32, R.FLAG_WAVEFRONT))
-for which in ("deep_bounce", "random_spheres", "cornell"):
+for which in ("deep_bounce", "random_spheres", "cornell", "mixed", "textured"):
     hs = getattr(HostScene, which)(w, h) if which == "cornell" else getattr(HostScene, which)(w, h, 1)
     sc = hs.upload()
     ref = None
