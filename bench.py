@@ -17,6 +17,7 @@ Rays are counted by the kernel: trace() invocations that traverse the scene (ray
 
 The one JSON line also carries
   roofline      the render kernel against the chip's peaks: algorithmic work per launch / HIP-event duration;
+  cpu_reference (extra) the unmodified reference binary oracle/_ref/ref_harness, one thread, bounded sample; absent if not built
   cpu_baseline  the oracle (CPU restatement of the reference, fp64) timed on this box's host cores on a bounded
                 sample of the same workload -- a reported baseline, not the target.
 """
@@ -79,6 +80,38 @@ def cpu_baseline(args, host_arrays):
                       f"{int(cnt[0])} rays in {dt:.2f} s (fp64, reference tree, OpenMP over rows, per-(pixel,sample) RNG streams)"}
 
 
+def cpu_reference(args, obj_path):
+    """The REAL reference (oracle/_ref/ref_harness: /root/reference's own sources, built in the dev container by `make -C oracle ref`;
+    the binary travels with the tree, the sources do not) on one host thread -- its best configuration: its OpenMP loop serialises on
+    rand()'s lock.  Bounded sample: the workload's scene at 1/3 of the resolution, 1 spp.  Returns None when the binary is not there."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(exe):
+        return None
+    w, h = max(args.width // 3, 16), max(args.height // 3, 16)
+    with tempfile.TemporaryDirectory() as tmp:
+        if args.workload == "random_spheres":
+            cmd = [exe, tmp, "time_c0", "1", str(w), str(h), "1", str(args.depth)]
+        else:
+            cmd = [exe, tmp, "time_obj", obj_path, str(w), str(h), "1", str(args.depth)] + [str(v) for v in OBJ_CAMERA[args.workload]]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+    rays = re.search(r"image \d+x\d+ spp=\d+ depth=\d+ rays=(\d+)", res.stdout)
+    secs = re.search(r"INFO time_\w+ seconds=([0-9.]+)", res.stdout)
+    if res.returncode != 0 or not rays or not secs:
+        return None
+    n, dt = int(rays.group(1)), float(secs.group(1))
+    return {"value": round(n / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+            "sample": f"{args.workload} {w}x{h}, 1 spp, max_depth {args.depth}: {n} rays in {dt:.2f} s (the reference's own trace() loop, single thread, rand())"}
+
+
+OBJ_CAMERA = {"obj": (0, 1.8, 5.0, 0, 1.0, 0, 40.0), "soup": (0, 5.0, 75.0, 0, 0, 0, 40.0)}     # position, look-at, fov of the OBJ workloads
+
+
 def main():
     args = parse()
     import torch
@@ -121,7 +154,7 @@ def main():
         from raytracing_amd.tools.make_mesh import write_soup
         obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_soup_{args.soup_tris}_r{rank}.obj")
         write_soup(obj_path, args.soup_tris, 64, args.soup_tex)
-        host = HostScene.obj(obj_path, w, h, 1, cam_pos=(0, 5.0, 75.0), cam_lookat=(0, 0, 0), fov=40.0)
+        host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["soup"][0:3], cam_lookat=OBJ_CAMERA["soup"][3:6], fov=OBJ_CAMERA["soup"][6])
         n_tri = int(host.desc.contents.n_prims)
         workload = (f"BASELINE configs[3]: {n_tri}-triangle soup in [-50,50]^3, 64 MTL materials each with a {args.soup_tex}^2 PNG map_Kd, emissive quad, "
                     f"through the OBJ loader and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
@@ -131,7 +164,7 @@ def main():
             from raytracing_amd.tools.make_mesh import write_scene
             obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_blob_l{args.mesh_level}_r{rank}.obj")
             n_tri = write_scene(obj_path, args.mesh_level)
-        host = HostScene.obj(obj_path, w, h, 1, cam_pos=(0, 1.8, 5.0), cam_lookat=(0, 1.0, 0), fov=40.0)
+        host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["obj"][0:3], cam_lookat=OBJ_CAMERA["obj"][3:6], fov=OBJ_CAMERA["obj"][6])
         n_tri = int(host.desc.contents.n_prims)
         workload = (f"BASELINE configs[2]: procedural OBJ mesh ({n_tri} triangles, diffuse/specular MTL + emissive quad) through the OBJ loader "
                     f"and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
@@ -240,6 +273,9 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, host.arrays())
+            ref = cpu_reference(args, obj_path if args.workload != "random_spheres" else None)
+            if ref:
+                out["cpu_reference"] = ref      # extra to the contract: the unmodified reference next to the multi-threaded port
         print(json.dumps(out), flush=True)
 
     scene.destroy()

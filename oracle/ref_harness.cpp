@@ -709,6 +709,26 @@ int main(int argc, char** argv)
         double t1 = omp_get_wtime();
         printf("INFO time_c0 seconds=%f\n", t1 - t0);
     }
+    else if (mode == "time_obj") {      // time_obj <path> <w> <h> <spp> <depth> <cam x y z> <lookat x y z> <fov> : the real reference on an OBJ scene, 1 thread
+        const char* path = argv[3];
+        int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+        vec3d pos(atof(argv[8]), atof(argv[9]), atof(argv[10])), at(atof(argv[11]), atof(argv[12]), atof(argv[13]));
+        double fov = atof(argv[14]);
+        srand(1);
+        built_scene* b = new built_scene();
+        b->scn = new scene(w, h);
+        loader* ld = new loader(path);
+        b->scn->add_object(ld->meshes());
+        b->scn->add_light(*ld->lights());
+        b->scn->set_camera(camera(pos, at, vec3d(0, 1, 0), fov, double(w) / h, 0, 1, 0, 1));
+        double tb = omp_get_wtime();
+        b->scn->build_bvh();
+        b->root = b->scn->objects.content()[0];
+        double t0 = omp_get_wtime();
+        do_image("time", b, w, h, spp, depth);
+        double t1 = omp_get_wtime();
+        printf("INFO time_obj seconds=%f bvh_seconds=%f\n", t1 - t0, t0 - tb);
+    }
     else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 1; }
     return 0;
 }
