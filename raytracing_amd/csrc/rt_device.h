@@ -123,7 +123,7 @@ template <typename R> struct Scene {
 };
 
 // `from`: id of the primitive the origin lies on (-1: none).  Only the fp32 modes read it, see prim_t.
-template <typename R> struct Ray { vec3<R> o, d; R time; int32_t from = -1; };
+template <typename R> struct Ray { vec3<R> o, d; R time = R(0); int32_t from = -1; };   // every member has a value from construction: no indeterminate lanes
 
 // ------------------------------------------------------------------ counter-based RNG
 // PCG32 XSH-RR over a state hashed from (seed, pixel, sample): nothing is stored between samples or launches,
@@ -436,10 +436,10 @@ template <typename R, bool kInst = true> __device__ inline bool prim_t(const Pri
 // hit record (intersection.hpp:13-27)
 template <typename R> struct Hit {
     vec3<R> pos, normal;
-    R u, v, t;
-    int32_t mat;
-    int32_t id;        // primitive id of the hit
-    bool front;
+    R u = R(0), v = R(0), t = R(0);
+    int32_t mat = 0;
+    int32_t id = -1;   // primitive id of the hit
+    bool front = false;
 };
 
 template <typename R> __device__ inline void set_face_normal(Hit<R>& h, const Ray<R>& r, const vec3<R>& n)  // intersection.hpp:22-26
@@ -851,6 +851,49 @@ template <typename R> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m
     }
 }
 
+#ifdef RT_OLD_SCATTER   // reproducer only (never built by the Makefile): the pre-fix shape, whole ray assigned inside every branch.  With it,
+                        // `tools/ray_count_parity.py` shows 2.7 % / 11 % of the pixels off in the register-resident fp32 kernels (hipcc 7.2, gfx950),
+                        // also with every Ray / Hit member initialised; optimisation barriers around the call or -ffp-contract=on hide it
+template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+                                                         Ray<R>& wo, vec3<R>& att, bool& spec)
+{
+    switch (m.kind) {
+    case RT_MAT_LAMBERTIAN:
+        spec = false;
+        wo.o = h.pos; wo.from = h.id; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
+        att = texc;
+        return true;
+    case RT_MAT_METAL: {
+        vec3<R> next = reflect(normalize(wi.d), h.normal);
+        vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
+        wo.o = h.pos; wo.from = h.id; wo.d = next + fuzz; wo.time = wi.time;
+        att = texc;
+        spec = true;
+        return true;
+    }
+    case RT_MAT_DIELECTRIC:
+        spec = true;
+        att = vec3<R>(R(1), R(1), R(1));
+        wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
+        return true;
+    case RT_MAT_PHONG: {
+        if (nz3(m.d + 7)) return false;
+        vec3<R> base = (m.tex >= 0) ? texc : vec3<R>(m.d[1], m.d[2], m.d[3]);
+        if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) { att = vec3<R>(m.d[4], m.d[5], m.d[6]); spec = true; return true; }
+        if (nz3(m.d + 10)) {
+            spec = true;
+            att = vec3<R>(m.d[10], m.d[11], m.d[12]);
+            wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
+            return true;
+        }
+        spec = false;
+        att = base;
+        return true;
+    }
+    default: return false;
+    }
+}
+#else
 template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
                                                          Ray<R>& wo, vec3<R>& att, bool& spec)
 {
@@ -860,6 +903,7 @@ template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m
     if (dir_set) { wo.o = h.pos; wo.from = h.id; wo.d = dir; wo.time = wi.time; }
     return true;
 }
+#endif
 
 template <typename R> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)
 {
