@@ -1,6 +1,6 @@
 // raytracing_amd/host/render_image.cpp -- the reference's driver (src/cpp/raytracing.cpp:73-137) on the GPU core:
 // same scene-building statements, the pixel/sample loop replaced by scene::render().
-//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell]
+//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell | features | smoke]
 // `render_image output.png 1024 1024 100 10 cornell` is the reference's own main() (raytracing.cpp:77-90,132-137).
 #include <chrono>
 #include <cstdio>
@@ -20,6 +20,15 @@ int main(int argc, char* argv[])
         scn.add_object(cornell_box());
         scn.add_light(new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30)))));
         scn.set_camera(camera(vec3d(278, 278, -800), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, 1, 0, 1, 0, 1));
+    }
+    else if (argc > 6 && (!std::strcmp(argv[6], "features") || !std::strcmp(argv[6], "smoke"))) {
+        // all_feature_test() (the reference's demo.hpp:94-143, which its main() never renders) / its sphere-bounded media alone.
+        // The demo's rect light is not flipped and shines upwards; here it is flipped so that the picture is lit.
+        const bool all = !std::strcmp(argv[6], "features");
+        scn.add_object(all ? all_feature_test() : smoke_scene());
+        if (all) scn.add_object(new flip(new planexz(123, 423, 147, 412, 553, new emissive(vec3d(7, 7, 7)))));
+        scn.add_light(new flip(new planexz(123, 423, 147, 412, all ? 553 : 554, new emissive(vec3d(7, 7, 7)))));
+        scn.set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(width) / height, 0, 10, 0, 1));
     }
     else if (argc > 6) {
         loader obj_loader(argv[6]);
