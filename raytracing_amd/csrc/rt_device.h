@@ -567,19 +567,49 @@ template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriSh
     R closest = t_max;
     int hit_side = -1;
     Prim<R> s;
-#pragma unroll 1
-    for (int i = 0; i < 6; i++) {                                        // group::intersect, group.hpp:68-83
-        side(i, s);
-        if (self) {
-            R oa, ob, ok;
-            plane_split(s.kind(), rr.o, oa, ob, ok);
-            const R scale = rt_abs(ok) > rt_abs(s.g[4]) ? rt_abs(ok) : rt_abs(s.g[4]);
-            if (rt_abs(s.g[4] - ok) <= R(2e-6) * (scale > R(1) ? scale : R(1))) continue;
+#ifndef RT_BOX_LOOP
+    if constexpr (sizeof(R) == sizeof(float)) {
+        // fp32: the closest of the six rects is the slab entry, or, from inside, the slab exit -- three reciprocals instead of six
+        // rect tests (the 400 ground boxes of all_feature_test() made this the hottest leaf code of that scene)
+        const R o[3] = { rr.o.x, rr.o.y, rr.o.z }, d[3] = { rr.d.x, rr.d.y, rr.d.z };
+        R t_in = -rt_inf<R>(), t_out = rt_inf<R>();
+        int side_in = -1, side_out = -1;
+        bool start_in = false, start_out = false;                        // the ray starts on a side and heads into / out of the box
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const R lo = p.g[k], hi = p.g[3 + k], inv = R(1) / d[k];
+            const R t_lo = (lo - o[k]) * inv, t_hi = (hi - o[k]) * inv;
+            const bool up = d[k] >= R(0);                                // enters through lo, leaves through hi
+            R tn = up ? t_lo : t_hi, tf = up ? t_hi : t_lo;
+            if (d[k] == R(0)) { const bool in = o[k] >= lo && o[k] <= hi; tn = in ? -rt_inf<R>() : rt_inf<R>(); tf = in ? rt_inf<R>() : -rt_inf<R>(); }
+            if (self) {
+                const R scale_lo = rt_abs(o[k]) > rt_abs(lo) ? rt_abs(o[k]) : rt_abs(lo), scale_hi = rt_abs(o[k]) > rt_abs(hi) ? rt_abs(o[k]) : rt_abs(hi);
+                const bool on_lo = rt_abs(lo - o[k]) <= R(2e-6) * (scale_lo > R(1) ? scale_lo : R(1));
+                const bool on_hi = rt_abs(hi - o[k]) <= R(2e-6) * (scale_hi > R(1) ? scale_hi : R(1));
+                if ((on_lo && up) || (on_hi && !up)) { start_in = true; tn = -rt_inf<R>(); }      // the side it starts on is not a candidate
+                if ((on_lo && !up) || (on_hi && up)) start_out = true;
+            }
+            const int pair = 2 - k;                                      // rect pairs in constructor order: z, y, x; even index = the max side
+            if (tn > t_in) { t_in = tn; side_in = pair * 2 + (up ? 1 : 0); }
+            if (tf < t_out) { t_out = tf; side_out = pair * 2 + (up ? 0 : 1); }
         }
-        R tt, a, b;
-        if (plane_t(s, rr, t_min, closest, tt, a, b)) { closest = tt; hit_side = i; }
+        if (start_out && !start_in) return false;                        // leaves the box at once: the other rects lie behind their bounds
+        if (!(t_in <= t_out)) return false;
+        if (t_in >= t_min && t_in <= closest && side_in >= 0) { closest = t_in; hit_side = side_in; }
+        else if (t_out >= t_min && t_out <= closest) { closest = t_out; hit_side = side_out; }
+        if (hit_side < 0) return false;
     }
-    if (hit_side < 0) return false;
+    else
+#endif
+    {
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {                                    // group::intersect, group.hpp:68-83
+            side(i, s);
+            R tt, a, b;
+            if (plane_t(s, rr, t_min, closest, tt, a, b)) { closest = tt; hit_side = i; }
+        }
+        if (hit_side < 0) return false;
+    }
     t = closest;
     if (h) {
         side(hit_side, s);
