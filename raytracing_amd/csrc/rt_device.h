@@ -399,7 +399,7 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
     }
 }
 
-template <typename R> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
+template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R a, b;
     if constexpr (sizeof(R) == sizeof(float)) {
@@ -414,23 +414,25 @@ template <typename R> __device__ inline bool prim_t_local(const Prim<R>& p, Side
     case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
-    case RT_PRIM_BOX: return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr);
-    case RT_PRIM_VOLUME: return volume_t<R>(p, r, t_min, t_max, t, g);
+    case RT_PRIM_BOX: if constexpr (kFull) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
+    case RT_PRIM_VOLUME: if constexpr (kFull) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
-// (kInst = false: the caller knows the scene has no instances -- the fast kernel is compiled both ways, the check costs it ~10 %)
-template <typename R, bool kInst = true> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
+// kFull: what the caller knows about the scene -- 0: spheres, rects and triangles only; 1: also boxes / volumes; 2: also instances.
+// The fast kernel is compiled for each: carrying the box, volume and instance code costs the sphere / triangle workloads 5-10 %,
+// the instance check costs the Cornell box 15 %.
+template <typename R, int kFull = 2> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
 {
-    const int xi = kInst ? p.xform() : -1;
-    if (kInst && xi >= 0) {
+    const int xi = kFull == 2 ? p.xform() : -1;
+    if (kFull == 2 && xi >= 0) {
         Ray<R> tr, rr;
         xform_rays(aux.xforms[xi], r, tr, rr);
-        return prim_t_local(p, aux, rr, t_min, t_max, t, g);
+        return prim_t_local<R, 2>(p, aux, rr, t_min, t_max, t, g);
     }
-    return prim_t_local(p, aux, r, t_min, t_max, t, g);
+    return prim_t_local<R, kFull>(p, aux, r, t_min, t_max, t, g);
 }
 
 // hit record (intersection.hpp:13-27)
@@ -450,8 +452,8 @@ template <typename R> __device__ inline void set_face_normal(Hit<R>& h, const Ra
 
 // Completes the record of a hit already known to lie at t on primitive p: the statements after the range test in
 // each intersect() (primitive.hpp:49-55, 123-129, 189-198; polygon.hpp:117-123; flip transform.hpp:134).
-template <typename R> __device__ inline void fill_record_local(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t,
-                                                               bool need_uv, Hit<R>& h)
+template <typename R, int kFull = 2> __device__ inline void fill_record_local(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t,
+                                                                                 bool need_uv, Hit<R>& h)
 {
     h.t = t;
     h.mat = p.mat;
@@ -487,8 +489,10 @@ template <typename R> __device__ inline void fill_record_local(const Prim<R>& p,
         break;
     }
     case RT_PRIM_BOX: {
-        R tt;
-        box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
+        if constexpr (kFull) {
+            R tt;
+            box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
+        }
         break;
     }
     case RT_PRIM_VOLUME:                                                    // primitive.hpp:379-383 (uv_coord is left as it was: 0 here)
@@ -513,15 +517,15 @@ template <typename R> __device__ inline void fill_record_local(const Prim<R>& p,
     if (p.flags() & RT_PRIM_FLAG_FLIP) h.front = !h.front;
 }
 
-template <typename R, bool kInst = true> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
+template <typename R, int kFull = 2> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
 {
-    const int xi = kInst ? p.xform() : -1;
-    if (!kInst || xi < 0) { fill_record_local(p, tris, r, t, need_uv, h); return; }
+    const int xi = kFull == 2 ? p.xform() : -1;
+    if (kFull != 2 || xi < 0) { fill_record_local<R, kFull>(p, tris, r, t, need_uv, h); return; }
     // member of an instance: the record is made in the instance's frame and comes back out through both wrappers' set_face_normal
     const Xform<R>& x = tris.xforms[xi];
     Ray<R> tr, rr;
     xform_rays(x, r, tr, rr);
-    fill_record_local(p, tris, rr, t, need_uv, h);
+    fill_record_local<R, 2>(p, tris, rr, t, need_uv, h);
     if (x.flags & RT_PRIM_FLAG_ROTATEY) {                                   // transform.hpp:99-110
         vec3<R> position = h.pos, normal = h.normal;
         position.x = x.cs * h.pos.x + x.sn * h.pos.z;
@@ -1038,7 +1042,7 @@ struct RenderArgs {
     // regenerate when at least regen_min lanes have no path (or none has one)
     uint32_t trav_keep, node_keep, regen_min;
     uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
-    uint32_t instances;                        // the scene has instance transforms (Scene::xforms)
+    uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances
 };
 
 // ------------------------------------------------------------------ render kernel

@@ -34,12 +34,14 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 #ifdef RT_WITH_FAST_BVH
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
             configured = lds;
@@ -47,16 +49,20 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     }
 #ifdef RT_WITH_FAST_BVH
     if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
-        if (a.instances) {      // scenes with instance transforms: the variant whose primitive tests look at them (unquantised nodes)
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, true>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, false, true>), grid, block, lds, s, sc, a, accum, counters);
+        if (a.kinds == 2) {     // scenes with instances: the variant whose primitive tests look at the transforms (unquantised nodes)
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);
+        }
+        else if (a.kinds == 1) {   // boxes or volumes
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 1>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, false, 1>), grid, block, lds, s, sc, a, accum, counters);
         }
         else if (a.quantised) {
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, true, false>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, true, false>), grid, block, lds, s, sc, a, accum, counters);
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, true, 0>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, true, 0>), grid, block, lds, s, sc, a, accum, counters);
         }
-        else if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, false>), grid, block, lds, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_wave_kernel<false, false, false>), grid, block, lds, s, sc, a, accum, counters);
+        else if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 0>), grid, block, lds, s, sc, a, accum, counters);
+        else hipLaunchKernelGGL((render_wave_kernel<false, false, 0>), grid, block, lds, s, sc, a, accum, counters);
         return hipGetLastError();
     }
     if (trav == 2) {

@@ -78,7 +78,7 @@ __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, fl
     tr = tnr; hr = tnr <= fmaf(tfr, 1.0000004f, t.slack);
 }
 
-template <bool kCount, bool kQuant, bool kInst>
+template <bool kCount, bool kQuant, int kFull>
 __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                     float t;
                     if (kCount && first_active_lane()) vs.w_leaf++;
                     if (kCount) vs.n_leaf++;
-                    if (prim_t<float, kInst>(fprims[first + k], sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
+                    if (prim_t<float, kFull>(fprims[first + k], sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
             }
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
             bool done = true;
             if (tv.hit >= 0) {
                 Hit<float> h;
-                fill_record<float, kInst>(fprims[tv.hit], sc.side(), ray, tv.closest, sc.need_uv != 0, h);
+                fill_record<float, kFull>(fprims[tv.hit], sc.side(), ray, tv.closest, sc.need_uv != 0, h);
                 const Mat<float>& m = sc.mats[h.mat];
                 const vec3<float> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<float>();
                 vec3<float> emission = mat_emit(m, h, texc);
