@@ -402,6 +402,10 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
 template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R a, b;
+    if constexpr (kFull == 3) {                                          // a scene of triangles only (what the OBJ loader builds)
+        if (sizeof(R) == sizeof(float) && p.id == r.from) return false;
+        return tri_t(p, r, t_min, t_max, t, a, b);
+    }
     if constexpr (sizeof(R) == sizeof(float)) {
         if (p.id == r.from && p.kind() != RT_PRIM_BOX && p.kind() != RT_PRIM_VOLUME) {   // (a box is tested again, without the side the ray starts on: see box_t;
                                                                                           //  a path scattered inside a medium is still inside it)
@@ -414,14 +418,15 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
     case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
     case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
-    case RT_PRIM_BOX: if constexpr (kFull) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
-    case RT_PRIM_VOLUME: if constexpr (kFull) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
+    case RT_PRIM_BOX: if constexpr (kFull == 1 || kFull == 2) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
+    case RT_PRIM_VOLUME: if constexpr (kFull == 1 || kFull == 2) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
-// kFull: what the caller knows about the scene -- 0: spheres, rects and triangles only; 1: also boxes / volumes; 2: also instances.
+// kFull: what the caller knows about the scene -- 0: spheres, rects and triangles only; 1: also boxes / volumes; 2: also instances;
+// 3: an OBJ-loader scene -- triangles only, every material a phong.
 // The fast kernel is compiled for each: carrying the box, volume and instance code costs the sphere / triangle workloads 5-10 %,
 // the instance check costs the Cornell box 15 %.
 template <typename R, int kFull = 2> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
@@ -459,7 +464,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
     h.mat = p.mat;
     h.id = p.id;
     h.u = h.v = R(0);
-    switch (p.kind()) {
+    switch (kFull == 3 ? RT_PRIM_TRIANGLE : p.kind()) {
     case RT_PRIM_SPHERE:
     case RT_PRIM_MSPHERE: {
         vec3<R> c = p.kind() == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);
@@ -489,7 +494,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         break;
     }
     case RT_PRIM_BOX: {
-        if constexpr (kFull) {
+        if constexpr (kFull == 1 || kFull == 2) {
             R tt;
             box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
         }
@@ -819,10 +824,11 @@ template <typename R> __device__ inline vec3<R> cosine_sample(Rng& g, const vec3
 
 // `texc`: the material's texture evaluated at the hit (tex_color draws no random numbers, so it is evaluated once, before the
 // per-material branches, for every lane whose material has one: one copy of the texture code, executed by all of them together)
-template <typename R> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const Hit<R>& h, const vec3<R>& texc)
+// kMat = 1: the caller knows every material of the scene is a phong (what the OBJ loader builds, loader.hpp:160)
+template <typename R, int kMat = 0> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const Hit<R>& h, const vec3<R>& texc)
 {
-    if (m.kind == RT_MAT_EMISSIVE) return h.front ? texc : vec3<R>();                                                   // material.hpp:146-154
-    if (m.kind == RT_MAT_PHONG) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
+    if (kMat != 1 && m.kind == RT_MAT_EMISSIVE) return h.front ? texc : vec3<R>();                                                   // material.hpp:146-154
+    if (kMat == 1 || m.kind == RT_MAT_PHONG) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
     return vec3<R>();
 }
 
@@ -833,11 +839,11 @@ template <typename R> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const 
 // with some flag combinations lanes on the dielectric branch came out with o.z and time of the scattered ray holding
 // temporaries of the other branches (found by comparing per-pixel ray counts with the fp64 mode; guarded by
 // tests/test_gpu_parity.py::test_fast_ray_counts_match_fp64_per_pixel).
-template <typename R> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
                                                          vec3<R>& dir, bool& dir_set, vec3<R>& att, bool& spec)
 {
     dir_set = true;
-    switch (m.kind) {
+    switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
         spec = false;
         dir = cosine_sample(g, h.normal);
@@ -888,10 +894,10 @@ template <typename R> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m
 #ifdef RT_OLD_SCATTER   // reproducer only (never built by the Makefile): the pre-fix shape, whole ray assigned inside every branch.  With it,
                         // `tools/ray_count_parity.py` shows 2.7 % / 11 % of the pixels off in the register-resident fp32 kernels (hipcc 7.2, gfx950),
                         // also with every Ray / Hit member initialised; optimisation barriers around the call or -ffp-contract=on hide it
-template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
                                                          Ray<R>& wo, vec3<R>& att, bool& spec)
 {
-    switch (m.kind) {
+    switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN:
         spec = false;
         wo.o = h.pos; wo.from = h.id; wo.d = cosine_sample(g, h.normal); wo.time = wi.time;
@@ -928,20 +934,20 @@ template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m
     }
 }
 #else
-template <typename R> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
-                                                         Ray<R>& wo, vec3<R>& att, bool& spec)
+template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
+                                                                       Ray<R>& wo, vec3<R>& att, bool& spec)
 {
     vec3<R> dir;
     bool dir_set = false;
-    if (!mat_scatter(g, m, wi, h, texc, dir, dir_set, att, spec)) return false;
+    if (!mat_scatter<R, kMat>(g, m, wi, h, texc, dir, dir_set, att, spec)) return false;
     if (dir_set) { wo.o = h.pos; wo.from = h.id; wo.d = dir; wo.time = wi.time; }
     return true;
 }
 #endif
 
-template <typename R> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)
+template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)
 {
-    switch (m.kind) {
+    switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN: {                                                               // material.hpp:37-41
         R c = dot(h.normal, normalize(wo.d));
         return c > R(0) ? c / consts<R>::pi : R(0);
@@ -1042,7 +1048,7 @@ struct RenderArgs {
     // regenerate when at least regen_min lanes have no path (or none has one)
     uint32_t trav_keep, node_keep, regen_min;
     uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
-    uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances
+    uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances, 3 triangles + phong only
 };
 
 // ------------------------------------------------------------------ render kernel

@@ -42,6 +42,8 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
             configured = lds;
@@ -52,6 +54,10 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
         if (a.kinds == 2) {     // scenes with instances: the variant whose primitive tests look at the transforms (unquantised nodes)
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);
+        }
+        else if (a.kinds == 3 && !a.quantised) {   // triangles only: what the OBJ loader builds
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 3>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, false, 3>), grid, block, lds, s, sc, a, accum, counters);
         }
         else if (a.kinds == 1) {   // boxes or volumes
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 1>), grid, block, lds, s, sc, a, accum, counters);
