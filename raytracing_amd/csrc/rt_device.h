@@ -402,7 +402,7 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
 template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R a, b;
-    if constexpr (kFull == 3) {                                          // a scene of triangles only (what the OBJ loader builds)
+    if constexpr (kFull >= 3) {                                          // a scene of triangles only (what the OBJ loader builds)
         if (sizeof(R) == sizeof(float) && p.id == r.from) return false;
         return tri_t(p, r, t_min, t_max, t, a, b);
     }
@@ -426,7 +426,7 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
 // kFull: what the caller knows about the scene -- 0: spheres, rects and triangles only; 1: also boxes / volumes; 2: also instances;
-// 3: an OBJ-loader scene -- triangles only, every material a phong.
+// 3: an OBJ-loader scene -- triangles only, every material a phong (4: the same, compiled for the occupancy of the other variants).
 // The fast kernel is compiled for each: carrying the box, volume and instance code costs the sphere / triangle workloads 5-10 %,
 // the instance check costs the Cornell box 15 %.
 template <typename R, int kFull = 2> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
@@ -464,7 +464,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
     h.mat = p.mat;
     h.id = p.id;
     h.u = h.v = R(0);
-    switch (kFull == 3 ? RT_PRIM_TRIANGLE : p.kind()) {
+    switch (kFull >= 3 ? RT_PRIM_TRIANGLE : p.kind()) {
     case RT_PRIM_SPHERE:
     case RT_PRIM_MSPHERE: {
         vec3<R> c = p.kind() == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);

@@ -44,6 +44,8 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
             configured = lds;
@@ -55,9 +57,13 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);
         }
-        else if (a.kinds == 3 && !a.quantised) {   // triangles only: what the OBJ loader builds
+        else if (a.kinds == 3 && !a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // OBJ-loader scene whose stack lets RT_WAVES_OBJ workgroups share a CU's LDS
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 3>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 3>), grid, block, lds, s, sc, a, accum, counters);
+        }
+        else if (a.kinds == 3 && !a.quantised) {   // ... a deeper tree: the same code at the other variants' occupancy
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 4>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, false, 4>), grid, block, lds, s, sc, a, accum, counters);
         }
         else if (a.kinds == 1) {   // boxes or volumes
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 1>), grid, block, lds, s, sc, a, accum, counters);

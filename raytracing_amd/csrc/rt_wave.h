@@ -16,6 +16,9 @@
 #pragma once
 
 #include "rt_device.h"
+#ifndef RT_WAVES_OBJ
+#define RT_WAVES_OBJ 5    // waves per SIMD of the OBJ-loader variant (96 VGPRs): measured 4 waves +11 % time, 6 waves +4 %; the other variants lose at 5
+#endif
 
 namespace rt {
 
@@ -79,7 +82,7 @@ __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, fl
 }
 
 template <bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
+__global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -226,20 +229,20 @@ __global__ void __launch_bounds__(256, RT_WAVES_FP32) render_wave_kernel(Scene<f
                 fill_record<float, kFull>(fprims[tv.hit], sc.side(), ray, tv.closest, sc.need_uv != 0, h);
                 const Mat<float>& m = sc.mats[h.mat];
                 const vec3<float> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<float>();
-                vec3<float> emission = mat_emit<float, kFull == 3>(m, h, texc);
+                vec3<float> emission = mat_emit<float, (kFull >= 3)>(m, h, texc);
                 Ray<float> wo; wo.time = 0.f;                                               // `ray wo;` raytracing.cpp:41
                 vec3<float> att;
                 bool spec = false;
                 L += beta * emission;
-                if (mat_shading<float, kFull == 3>(g, m, ray, h, texc, wo, att, spec)) {
+                if (mat_shading<float, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec)) {
                     float pdf, mpdf;
                     if (spec) {                                                             // raytracing.cpp:51-54
-                        mpdf = mat_pdf<float, kFull == 3>(g, m, h, wo);
+                        mpdf = mat_pdf<float, (kFull >= 3)>(g, m, h, wo);
                         pdf = mpdf;
                     }
                     else {                                                                  // raytracing.cpp:55-61
                         if (uniform<float>(g) < 0.5f) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
-                        mpdf = mat_pdf<float, kFull == 3>(g, m, h, wo);
+                        mpdf = mat_pdf<float, (kFull >= 3)>(g, m, h, wo);
                         pdf = 0.5f * (lights_pdf(sc, h.pos, wo.d) + mpdf);
                     }
                     float inv = 1.0f / pdf;                                                 // raytracing.cpp:69, vec3.hpp:121-123
