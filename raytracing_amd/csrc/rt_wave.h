@@ -112,10 +112,11 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
 
     bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
-    int depth = 0, path_rays = 0, local = 0;
+    int depth = 0, local = 0;
     Rng g; g.s = 0;
     Ray<float> ray;
-    vec3<float> beta, L;
+    vec3<float> beta;      // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
+                           // :215), so the only non-zero term of L = sum beta_i * emission_i is the last hit's
     Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f;
 
     unsigned long long census[3] = { 0, 0, 0 };
@@ -147,10 +148,8 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                         float y = (float(i) + uniform<float>(g)) / float(a.height - 1);
                         ray = camera_emit(sc.cam, g, x, y);
                         beta = vec3<float>(1.f, 1.f, 1.f);
-                        L = vec3<float>();
                         depth = a.max_depth;
                         poisoned = false;
-                        path_rays = 0;
                         alive = true;
                         trav_begin(tv, ray);
                     }
@@ -221,7 +220,8 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
         // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
         if (alive && tv.cur == RT_BVH_SENTINEL) {
             n_rays++;
-            path_rays++;
+            const int path_rays = a.max_depth - depth + 1;               // this path's segments so far, this one included
+            vec3<float> L;
             if (kCount && first_active_lane()) vs.w_bounce++;
             bool done = true;
             if (tv.hit >= 0) {
@@ -233,7 +233,6 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                 Ray<float> wo; wo.time = 0.f;                                               // `ray wo;` raytracing.cpp:41
                 vec3<float> att;
                 bool spec = false;
-                L += beta * emission;
                 if (mat_shading<float, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec)) {
                     float pdf, mpdf;
                     if (spec) {                                                             // raytracing.cpp:51-54
@@ -247,13 +246,15 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     }
                     float inv = 1.0f / pdf;                                                 // raytracing.cpp:69, vec3.hpp:121-123
                     vec3<float> w = mpdf * att;
-                    if (!rt_finite(inv) || !rt_finite(w.x) || !rt_finite(w.y) || !rt_finite(w.z)) poisoned = true;
                     beta = beta * (inv * w);
+                    // a non-finite 1/pdf or weight (also 0 * inf) poisons the sample whatever follows: the recursion multiplies it in
+                    if (!rt_finite(beta.x) || !rt_finite(beta.y) || !rt_finite(beta.z)) poisoned = true;
                     ray = wo;
                     depth--;
                     done = depth <= 0;
                     if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
                 }
+                else L = beta * emission;                                                   // the path ends on an emitter (or absorber)
             }
             if (done) {
                 alive = false;
