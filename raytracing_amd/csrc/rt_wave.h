@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     const Prim<float>* __restrict__ fprims = sc.fprims;
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
 
-    unsigned long long n_rays = 0, n_rejected = 0;
+    uint32_t lane_rays = 0, lane_rejected = 0;     // per lane (32 bits are plenty: a lane's share of one tile), widened for the reduction
     VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
 
     bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
 
         // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
         if (alive && tv.cur == RT_BVH_SENTINEL) {
-            n_rays++;
+            lane_rays++;
             const int path_rays = a.max_depth - depth + 1;               // this path's segments so far, this one included
             vec3<float> L;
             if (kCount && first_active_lane()) vs.w_bounce++;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
             if (done) {
                 alive = false;
                 bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
-                if (bad) n_rejected++;
+                if (bad) lane_rejected++;
                 if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<float>(float(path_rays), bad ? 1.f : 0.f, 0.f); bad = false; }
                 if (!bad) {
                     float* dst = tile_sum + local * 3;
@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     }
 
     // wave-level reduction of the counters, one atomic pair per wave
+    unsigned long long n_rays = lane_rays, n_rejected = lane_rejected;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         n_rays += __shfl_down(n_rays, off, 64);
