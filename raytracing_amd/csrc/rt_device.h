@@ -1049,6 +1049,7 @@ struct RenderArgs {
     uint32_t trav_keep, node_keep, regen_min;
     uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
     uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances, 3 triangles + phong only
+    uint32_t xcd_tiles;                        // != 0: rt_wave.h deals 8 x 8-tile super-tiles to the 8 XCDs (grid padded to whole rounds of 8 super-tiles)
 };
 
 // ------------------------------------------------------------------ render kernel

@@ -53,6 +53,7 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     }
 #ifdef RT_WITH_FAST_BVH
     if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
+        if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64)); }
         if (a.kinds == 2) {     // scenes with instances: the variant whose primitive tests look at the transforms (unquantised nodes)
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);

@@ -85,6 +85,21 @@ template <bool kCount, bool kQuant, int kFull>
 __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
+    // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut
+    // into super-tiles of 8 x 8 tiles, dealt to the XCDs round-robin (neighbouring super-tiles cost about the same, so the XCDs
+    // stay balanced), and the tiles an XCD has in flight are two or three compact 128 x 128-pixel blocks rather than every
+    // eighth tile of a strip across the image
+    const int tiles_x = (a.width + 15) >> 4;
+    int tile_x, tile_y;
+    if (a.xcd_tiles) {
+        const int tiles_y = (a.y_end - a.y_begin + 15) >> 4;
+        const int stx = (tiles_x + 7) >> 3;
+        const int s = (int) (blockIdx.x >> 3), super = (s >> 6) * 8 + (int) (blockIdx.x & 7u), within = s & 63;
+        const int sy = super / stx, sx = super - sy * stx;
+        tile_x = sx * 8 + (within & 7); tile_y = sy * 8 + (within >> 3);
+        if (tile_x >= tiles_x || tile_y >= tiles_y) return;                   // whole workgroup, before any barrier
+    }
+    else { tile_x = (int) (blockIdx.x % (unsigned) tiles_x); tile_y = (int) (blockIdx.x / (unsigned) tiles_x); }
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;       // entry `level` of this lane: stack[level * 256]
     float* tile_sum = reinterpret_cast<float*>(smem + a.lds_tile_offset);
@@ -94,8 +109,6 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     stack[0] = (uint32_t) RT_BVH_SENTINEL;
     __syncthreads();
 
-    const int tiles_x = (a.width + 15) >> 4;
-    const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const int lane = threadIdx.x & 63;
     auto pixel_of = [&](int local, int& jj, int& ii) {       // slot 0..255 of the 16x16 tile: waves are 8x8 sub-tiles
         const int wv = local >> 6, ln = local & 63;

@@ -189,14 +189,17 @@ class Scene:
                     leaf_tests=int(st.leaf_tests), wave_node_steps=int(st.wave_node_steps), wave_leaf_steps=int(st.wave_leaf_steps),
                     wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks]) if want_stats else None
 
-    def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0):
-        """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats)."""
+    def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0, y_begin=0, y_end=None):
+        """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats).  With a row
+        sub-range the buffer starts zeroed, so rows outside it read as zero."""
         dt = np.float64 if mode == MODE_REFERENCE_FP64 else np.float32
         n = width * height * 3
         acc = DeviceBuffer(n * np.dtype(dt).itemsize)
         rgb = DeviceBuffer(n)
         try:
-            stats = self.render(acc.ptr, width, height, spp_begin, spp_end, max_depth, mode, seed, flags)
+            if y_begin != 0 or y_end not in (None, height):
+                acc.upload(np.zeros(n, dt))
+            stats = self.render(acc.ptr, width, height, spp_begin, spp_end, max_depth, mode, seed, flags, y_begin, y_end)
             resolve(acc.ptr, mode == MODE_REFERENCE_FP64, width * height, spp_end - spp_begin, rgb.ptr)
             return acc.download(dt, (height, width, 3)), rgb.download(np.uint8, (height, width, 3)), stats
         finally:

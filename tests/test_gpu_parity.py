@@ -477,4 +477,26 @@ def test_bad_arguments_are_errors_not_crashes(R):
     sc.first_hit(np.array([[13, 2, 3, -13, -2, -3, 0.5]]))    # first-hit needs no lights
     acc.free()
     sc.destroy()
-    osc.free()
+    osc.free()@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,rows", [(200, 140, (0, 140)), (129, 17, (0, 17)), (272, 260, (37, 203))])
+def test_xcd_super_tile_order_renders_the_same_pixels(R, monkeypatch, w, h, rows):
+    """The fast kernel's XCD-aware tile order (rt_wave.h: 8 x 8-tile super-tiles dealt round-robin to the XCDs, on by default only
+    for scenes larger than one L2) is a permutation of the tiles: with per-pixel ray counts as the output (exact integers,
+    independent of the order of the fp32 tile additions) both orders must give the same array, also for images whose size is no
+    multiple of the super-tile, for a row sub-range, and outside the rows nothing may be written."""
+    from raytracing_amd.host_scenes import HostScene
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("RT_XCD_TILES", on)
+        hs = HostScene.random_spheres(w, h, 1)
+        sc = hs.upload()
+        out[on] = sc.render_to_host(w, h, 0, 4, 50, R.MODE_FAST_FP32, seed=9, flags=R.FLAG_DEBUG_RAY_COUNTS, y_begin=rows[0], y_end=rows[1])
+        sc.destroy()
+        hs.free()
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a[0], b[0])
+    assert a[2]["rays"] == b[2]["rays"] and a[2]["rays"] == int(a[0][..., 0].sum())
+    assert not a[0][:rows[0]].any() and not a[0][rows[1]:].any() and a[0][rows[0]:rows[1], :, 0].min() >= 1
+
+
+
