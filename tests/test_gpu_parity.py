@@ -477,7 +477,9 @@ def test_bad_arguments_are_errors_not_crashes(R):
     sc.first_hit(np.array([[13, 2, 3, -13, -2, -3, 0.5]]))    # first-hit needs no lights
     acc.free()
     sc.destroy()
-    osc.free()@pytest.mark.gpu
+    osc.free()
+
+
 @pytest.mark.parametrize("w,h,rows", [(200, 140, (0, 140)), (129, 17, (0, 17)), (272, 260, (37, 203))])
 def test_xcd_super_tile_order_renders_the_same_pixels(R, monkeypatch, w, h, rows):
     """The fast kernel's XCD-aware tile order (rt_wave.h: 8 x 8-tile super-tiles dealt round-robin to the XCDs, on by default only
@@ -497,6 +499,3 @@ def test_xcd_super_tile_order_renders_the_same_pixels(R, monkeypatch, w, h, rows
     assert np.array_equal(a[0], b[0])
     assert a[2]["rays"] == b[2]["rays"] and a[2]["rays"] == int(a[0][..., 0].sum())
     assert not a[0][:rows[0]].any() and not a[0][rows[1]:].any() and a[0][rows[0]:rows[1], :, 0].min() >= 1
-
-
-
