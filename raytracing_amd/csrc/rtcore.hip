@@ -441,14 +441,6 @@ __global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n
     for (int i = 0; i < n; i++) out[i] = g.next();
 }
 
-}  // namespace
-
-extern "C" {
-
-}  // extern "C"
-
-namespace {
-
 // path pool of the wavefront renderer (rt_wavefront.h): allocated once per scene
 int wf_prepare(rt_scene* s)
 {
@@ -821,7 +813,8 @@ int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t
     uint32_t* d = nullptr;
     HIP_TRY(hipMalloc((void**) &d, (size_t) n * 4));
     hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, nullptr, seed, pixel, sample, n, d);
-    hipError_t e = hipMemcpy(out_host, d, (size_t) n * 4, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_host, d, (size_t) n * 4, hipMemcpyDeviceToHost);
     (void) hipFree(d);
     if (e != hipSuccess) return fail(RT_EHIP, hipGetErrorString(e));
     return RT_OK;
