@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 # (fma = 2) and half a 64-B node record; per leaf test ~40 flop (triangle: 2 cross, 4 dot, 1 rcp; sphere: 3 dots, disc, sqrt,
 # div) and one 48-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
 FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
-BYTES_BOX, BYTES_LEAF = 32.0, 48.0   # fast tree: one 64-B node record per two box tests
+BYTES_LEAF = 48.0   # fast tree: one node record (64 B, or 32 B quantised) per two box tests, one 48-B record per leaf test
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 PEAK_L1_GBS = 256 * 64 * 2.4   # vector L1 (TCP) -> register path: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s; the unit that binds the node loop
@@ -222,14 +222,17 @@ def main():
         rays_per_launch = rays / max(args.steps, 1)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         flop_per_ray = box_per_ray * FLOP_BOX + leaf_per_ray * FLOP_LEAF + FLOP_SHADE
-        bytes_per_ray = box_per_ray * BYTES_BOX + leaf_per_ray * BYTES_LEAF
+        # OBJ-loader scenes (triangles + phong only) walk the 32-byte quantised nodes by default (rtcore.hip, RT_QNODES overrides)
+        quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and args.mode == "fp32"
+        node_bytes = 32.0 if quantised else 64.0
+        bytes_per_ray = box_per_ray * node_bytes / 2 + leaf_per_ray * BYTES_LEAF
         if args.mode == "fp64":
             bytes_per_ray = box_per_ray * 56.0 + leaf_per_ray * 112.0
         achieved_tflops = rays_per_launch * flop_per_ray / (avg_ms * 1e-3) / 1e12
         fetch_gbs = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
         peak = PEAK_FP32_TFLOPS if args.mode != "fp64" else PEAK_FP32_TFLOPS / 2
         d = host.desc.contents
-        scene_mb = (d.n_prims * 64 * 0.6 + d.n_prims * 48) / 1e6      # ~0.6 SAH nodes per primitive x 64 B + 48 B primitive records
+        scene_mb = (d.n_prims * node_bytes * 0.6 + d.n_prims * 48) / 1e6      # ~0.6 SAH nodes per primitive + 48 B primitive records
         # HBM-side bytes per launch: bytes per ray measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload at reduced spp (profiles/hbm_traffic.json, written by
         # tools/hbm_traffic.py), scaled by this launch's ray count; null when no measurement of this workload is on file
@@ -247,14 +250,17 @@ def main():
                   "flop_per_ray": round(flop_per_ray, 1), "scene_bytes_per_ray": round(bytes_per_ray, 1), "scene_MB": round(scene_mb, 1),
                   "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1),
                   "l1_peak_GBs": round(PEAK_L1_GBS, 0), "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4),
-                  "binding_limit": "vector L1 bandwidth (64 B/clk/CU): every node visit moves a 64-B record per lane through the texture-addresser/L1 path; "
-                                   "PMC TA_TA_BUSY 72-80 %, VALU 47-54 % busy on the mesh, lane utilisation of the node loop ~48 %"}
+                  "node_record_bytes": node_bytes,
+                  "binding_limit": "vector L1 line-lookup rate: a divergent 16-B load costs one cache-line lookup per ACTIVE lane per clock per CU "
+                                   "(tools/ta_mask_bench.hip: 150 G random 64-B records/s chip-wide whatever the lane mask), so every node visit "
+                                   "costs 4 lookups per lane (2 with 32-B nodes) and idle lanes cost nothing; PMC TA_TA_BUSY 72-80 %, VALU 47-54 % "
+                                   "busy on the mesh with 64-B nodes (53 % / 68 % with 32-B nodes)"}
         if scene_mb > 32.0:
-            # node + primitive records do not fit the 8 x 4 MiB L2s: every visit is a 64-B record fetch from beyond L2
+            # node + primitive records do not fit the 8 x 4 MiB L2s: every visit is a record fetch from beyond L2
             # (Infinity Cache / HBM).  achieved = algorithmic record bytes (tests per ray from the kernel's own counters x
             # record sizes) / kernel time, against the HBM peak.
             roofline = dict(common, bound="hbm", achieved=round(fetch_gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(fetch_gbs / PEAK_HBM_GBS, 4),
-                            note="algorithmic bytes = box_tests/2 x 64-B node + leaf_tests x 48-B primitive record per ray; records are served by "
+                            note="algorithmic bytes = box_tests/2 x node record (node_record_bytes) + leaf_tests x 48-B primitive record per ray; records are served by "
                                  "L1/L2 + the 256 MiB Infinity Cache as well as HBM (traffic = memory-side bytes), so achieved can approach or "
                                  "pass the HBM-only peak; the kernel's binding limits are VALU issue and the vector-memory address path, see valu_TFLOPs")
         else:

@@ -44,6 +44,8 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
@@ -58,7 +60,11 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);
         }
-        else if (a.kinds == 3 && !a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // OBJ-loader scene whose stack lets RT_WAVES_OBJ workgroups share a CU's LDS
+        else if (a.kinds == 3 && a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // OBJ-loader scene, 32-byte nodes (the default for it), RT_WAVES_OBJ workgroups share a CU's LDS
+            if (count) hipLaunchKernelGGL((render_wave_kernel<true, true, 3>), grid, block, lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave_kernel<false, true, 3>), grid, block, lds, s, sc, a, accum, counters);
+        }
+        else if (a.kinds == 3 && !a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // ... with 64-byte nodes (RT_QNODES=0)
             if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 3>), grid, block, lds, s, sc, a, accum, counters);
             else hipLaunchKernelGGL((render_wave_kernel<false, false, 3>), grid, block, lds, s, sc, a, accum, counters);
         }

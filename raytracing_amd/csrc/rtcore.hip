@@ -507,6 +507,9 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     // measured optima (tools/sweep_wave.py, 4K): small scenes spend as much time shading as traversing and want fuller shading
     // passes (64/64); big meshes are traversal-bound and want fuller node steps (96/128)
     if (desc->n_prims < 4096) { s->trav_keep = 64; s->node_keep = 64; }
+    // 32-byte nodes trade vector-L1 line lookups (two loads per node instead of four) for decode arithmetic: a gain only where
+    // the kernel has arithmetic to spare, the lean OBJ-loader variant at 5 waves/SIMD (mesh workload -4 % time, 5.2 M triangles -2.5 %)
+    s->quantised = s->only_triangles;
     if (const char* env = std::getenv("RT_QNODES")) s->quantised = std::atoi(env) != 0;
     // measured at 4K: 1.3 M triangles -1.4 % time, 5.2 M triangles -2.3 %; 485 spheres (everything L1/L2-resident anyway) +1..4 %
     s->xcd_tiles = (size_t) s->d32.view.n_bnodes * sizeof(rt::BNode) + (size_t) desc->n_prims * sizeof(rt::Prim<float>) > (4u << 20);
