@@ -80,9 +80,12 @@ struct alignas(16) BNode {
 };
 // The same node in 32 B (two 16-byte loads instead of four): the vector-memory address path is the busiest unit of the
 // traversal on meshes (~18 TA cycles per load instruction, PMC TA_TA_BUSY ~80 %), so halving the loads per node visit pays
-// for the decode.  Per axis a: o[a] = the 24 high bits of a float origin <= both boxes' minima | the biased exponent of a
-// power-of-two step; q[a] = four bytes: left lo, left hi, right lo, right hi in steps from the origin (lo rounded down, hi up,
-// after padding by the fp32 decode error, so the decoded boxes contain the real ones).
+// for the decode.  Per axis a: o[a] = a float origin <= both boxes' minima whose low byte is the (signed) exponent e of a
+// power-of-two step -- the kernel uses the whole dword as the origin, exponent bits included, and the builder accounts for
+// them; q[a] = four bytes: left lo, right lo, left hi, right hi in steps from the origin (lo rounded down, hi up, after
+// padding by the fp32 decode error, so the decoded boxes contain the real ones).  lo <= hi byte-wise, so which plane a ray
+// meets first follows from the sign of its direction alone: a ray going down the axis rotates the dword by 16 bits and reads
+// near planes from bytes 0-1, far planes from bytes 2-3 -- no min / max per plane pair.
 struct alignas(16) QNode {
     uint32_t o[3];
     uint32_t q[3];

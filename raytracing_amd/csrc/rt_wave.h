@@ -27,6 +27,7 @@ struct Trav {                 // per-lane traversal state, kept across phases
     float slack;              // absolute slack of the slab comparison (rounding of o/d)
     float closest;
     int32_t hit, cur, sp;
+    uint32_t rot;             // quantised nodes: per axis (byte a) 16 if the ray goes down the axis, else 0
 };
 
 __device__ inline void trav_begin(Trav& t, const Ray<float>& r)
@@ -37,6 +38,7 @@ __device__ inline void trav_begin(Trav& t, const Ray<float>& r)
     t.noid = vec3<float>(-r.o.x * t.idir.x, -r.o.y * t.idir.y, -r.o.z * t.idir.z);
     // t = fma(plane, idir, -o*idir) rounds once; what is left is the rounding of o*idir itself (<= 1/2 ulp of it)
     t.slack = 2.4e-7f * fmaxf(fmaxf(fabsf(t.noid.x), fabsf(t.noid.y)), fabsf(t.noid.z));
+    t.rot = (t.idir.x < 0.f ? 16u : 0u) | (t.idir.y < 0.f ? 16u << 8 : 0u) | (t.idir.z < 0.f ? 16u << 16 : 0u);
     t.closest = rt_inf<float>();
     t.hit = -1;
     t.cur = 0;
@@ -54,29 +56,21 @@ __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, floa
     hit = tn <= fmaf(tf, 1.0000004f, t.slack);     // conservative under fp32 rounding
 }
 
-// both children of a quantised node: per axis t = q * (step * idir) + (origin * idir - o * idir)
+// both children of a quantised node (rt_device.h QNode): per axis t = q * (step * idir) + (origin * idir - o * idir), near planes in
+// bytes 0-1 and far planes in bytes 2-3 once the dword is rotated for the ray's direction (Trav::rot)
 __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
 {
-    float x[4], y[4], z[4];
-    {
-        const float A = __uint_as_float((n.o[0] & 0xffu) << 23) * t.idir.x, B = fmaf(__uint_as_float(n.o[0] & 0xffffff00u), t.idir.x, t.noid.x);
+    float ln[3], rn[3], lf[3], rf[3];
+    const float idir[3] = { t.idir.x, t.idir.y, t.idir.z }, noid[3] = { t.noid.x, t.noid.y, t.noid.z };
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = fmaf(float((n.q[0] >> (8 * k)) & 0xffu), A, B);
+    for (int a = 0; a < 3; a++) {
+        const float A = ldexpf(idir[a], (int) (int8_t) (n.o[a] & 0xffu)), B = fmaf(__uint_as_float(n.o[a]), idir[a], noid[a]);
+        const uint32_t q = __builtin_amdgcn_alignbit(n.q[a], n.q[a], t.rot >> (8 * a));      // the hardware reads 5 bits of the shift: 0 or 16
+        ln[a] = fmaf(float(q & 0xffu), A, B); rn[a] = fmaf(float((q >> 8) & 0xffu), A, B);
+        lf[a] = fmaf(float((q >> 16) & 0xffu), A, B); rf[a] = fmaf(float(q >> 24), A, B);
     }
-    {
-        const float A = __uint_as_float((n.o[1] & 0xffu) << 23) * t.idir.y, B = fmaf(__uint_as_float(n.o[1] & 0xffffff00u), t.idir.y, t.noid.y);
-#pragma unroll
-        for (int k = 0; k < 4; k++) y[k] = fmaf(float((n.q[1] >> (8 * k)) & 0xffu), A, B);
-    }
-    {
-        const float A = __uint_as_float((n.o[2] & 0xffu) << 23) * t.idir.z, B = fmaf(__uint_as_float(n.o[2] & 0xffffff00u), t.idir.z, t.noid.z);
-#pragma unroll
-        for (int k = 0; k < 4; k++) z[k] = fmaf(float((n.q[2] >> (8 * k)) & 0xffu), A, B);
-    }
-    const float tnl = fmaxf(fmaxf(fminf(x[0], x[1]), fminf(y[0], y[1])), fmaxf(fminf(z[0], z[1]), t_min));
-    const float tfl = fminf(fminf(fmaxf(x[0], x[1]), fmaxf(y[0], y[1])), fminf(fmaxf(z[0], z[1]), t.closest));
-    const float tnr = fmaxf(fmaxf(fminf(x[2], x[3]), fminf(y[2], y[3])), fmaxf(fminf(z[2], z[3]), t_min));
-    const float tfr = fminf(fminf(fmaxf(x[2], x[3]), fmaxf(y[2], y[3])), fminf(fmaxf(z[2], z[3]), t.closest));
+    const float tnl = fmaxf(fmaxf(ln[0], ln[1]), fmaxf(ln[2], t_min)), tfl = fminf(fminf(lf[0], lf[1]), fminf(lf[2], t.closest));
+    const float tnr = fmaxf(fmaxf(rn[0], rn[1]), fmaxf(rn[2], t_min)), tfr = fminf(fminf(rf[0], rf[1]), fminf(rf[2], t.closest));
     tl = tnl; hl = tnl <= fmaf(tfl, 1.0000004f, t.slack);
     tr = tnr; hr = tnr <= fmaf(tfr, 1.0000004f, t.slack);
 }
@@ -130,7 +124,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     Ray<float> ray;
     vec3<float> beta;      // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
                            // :215), so the only non-zero term of L = sum beta_i * emission_i is the last hit's
-    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f;
+    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
 
     unsigned long long census[3] = { 0, 0, 0 };
     unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // diagnostic: wave time per phase (regenerate, nodes, leaves, shade)
