@@ -56,6 +56,13 @@ __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, floa
     hit = tn <= fmaf(tf, 1.0000004f, t.slack);     // conservative under fp32 rounding
 }
 
+// record at a 32-bit byte offset from a wave-uniform base: one 32-bit multiply / shift and the scalar-base addressing mode instead
+// of 64-bit address arithmetic per lane (rtcore.hip refuses trees or record arrays beyond 4 GiB)
+template <typename T> __device__ inline const T* at32(const T* base, uint32_t byte_offset)
+{
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
+
 // both children of a quantised node (rt_device.h QNode): per axis t = q * (step * idir) + (origin * idir - o * idir), near planes in
 // bytes 0-1 and far planes in bytes 2-3 once the dword is rotated for the ray's direction (Trav::rot)
 __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
@@ -185,12 +192,12 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     float tl, tr; bool hl, hr;
                     int32_t c_left, c_right;
                     if (kQuant) {
-                        const QNode n = sc.qnodes[tv.cur];
+                        const QNode n = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
                         slab_quant(n, tv, t_min, tl, hl, tr, hr);
                         c_left = n.left; c_right = n.right;
                     }
                     else {
-                        const BNode n = nodes[tv.cur];
+                        const BNode n = *at32(nodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
                         slab_fma(n.lb, tv, t_min, tl, hl);
                         slab_fma(n.rb, tv, t_min, tr, hr);
                         c_left = n.left; c_right = n.right;
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     // the whole 48-byte record in one round trip (three 16-byte loads issued together): left to itself the compiler
                     // sinks each field's load into the branch that first needs it -- id, then the edges, then the vertex: three
                     // dependent memory latencies per triangle (mesh workload -4.6 % time, leaf share of the wave time 21 -> 13 %)
-                    Prim<float> rec = fprims[first + k];
+                    Prim<float> rec = *at32(fprims, (uint32_t) (first + k) * (uint32_t) sizeof(Prim<float>));
                     asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
                     if (prim_t<float, kFull>(rec, sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
                 }

@@ -296,6 +296,8 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     if (const char* e = std::getenv("RT_BVH_CPRIM")) c_prim = std::atof(e);
     rtb::Tree tree = rtb::Builder(items, leaf_max, c_prim).build();
     if (tree.depth + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode tree deeper than the traversal stack");
+    if (tree.nodes.size() * sizeof(rt::BNode) >= (1ull << 32) || tree.order.size() * sizeof(rt::Prim<float>) >= (1ull << 32))
+        return fail(RT_EUNSUPPORTED, "fast-mode tree or record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");
     std::vector<rt::BNode> nodes(tree.nodes.size());
     for (size_t i = 0; i < nodes.size(); i++) {
         std::memset(&nodes[i], 0, sizeof(rt::BNode));
