@@ -38,7 +38,15 @@ struct Tree {
 
 class Builder {
 public:
-    Builder(std::vector<Item>& items, int max_leaf, double cost_prim) : it(items), leaf_max(std::max(1, std::min(max_leaf, 8))), c_prim(cost_prim) {}
+    // depth_limit: no leaf deeper than this (the traversal stack lives in LDS and its size decides how many workgroups share a
+    // CU).  A split whose larger side could not be finished within the limit even by halving is replaced by a median split, so the
+    // limit holds whenever 1 + balanced_height(n) <= depth_limit; otherwise the builder falls back to RT_BUILD_SAH_DEPTH.
+    Builder(std::vector<Item>& items, int max_leaf, double cost_prim, int depth_limit = RT_BUILD_SAH_DEPTH)
+        : it(items), leaf_max(std::max(1, std::min(max_leaf, 8))), c_prim(cost_prim), limit(depth_limit)
+    {
+        if (1 + balanced_height((int) items.size()) > limit) limit = std::max(limit, (int) RT_BUILD_SAH_DEPTH);
+    }
+    int balanced_height(int n) const { int h = 0; while (n > leaf_max) { n = (n + 1) / 2; h++; } return h; }
 
     Tree build()
     {
@@ -74,6 +82,7 @@ private:
     std::vector<Item>& it;
     int leaf_max;
     double c_prim;
+    int limit;
     Tree* tree = nullptr;
     static const int kBins = 16;
 
@@ -118,7 +127,7 @@ private:
             }
         }
         double leaf_cost = c_prim * n;
-        if (n <= leaf_max && (best_axis < 0 || leaf_cost <= best_cost)) return make_leaf(b, e);
+        if (n <= leaf_max && (best_axis < 0 || leaf_cost <= best_cost || depth >= limit)) return make_leaf(b, e);
         int mid;
         if (best_axis >= 0) {
             double ext = cb.hi[best_axis] - cb.lo[best_axis], scale = kBins / ext, lo = cb.lo[best_axis];
@@ -136,6 +145,13 @@ private:
             std::nth_element(it.begin() + b, it.begin() + mid, it.begin() + e, [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis]; });
         }
         if (mid == b || mid == e) mid = b + n / 2;
+        if (depth + 1 + balanced_height(std::max(mid - b, e - mid)) > limit && depth + balanced_height(n) <= limit) {
+            // the larger side could not be finished within the depth limit: halve instead (along the widest axis of the centroids)
+            int axis = 0;
+            for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+            mid = b + (n + 1) / 2;
+            std::nth_element(it.begin() + b, it.begin() + mid, it.begin() + e, [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis]; });
+        }
         Box lb, rb;
         for (int i = b; i < mid; i++) lb.grow(it[i].box);
         for (int i = mid; i < e; i++) rb.grow(it[i].box);

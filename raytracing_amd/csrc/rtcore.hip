@@ -291,10 +291,17 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         for (int32_t p : f.op_prim)
             if (p >= 0 && d->prim_kind[p] == RT_PRIM_VOLUME && seen[p]++ > 0) items.push_back(items[p]);
     }
-    int leaf_max = 4; double c_prim = 1.5;
+    // cost of a primitive test relative to a node step, measured (4K sweeps): triangles 1.0 (mesh workload -2.8 % time against 1.5),
+    // scenes with spheres 1.5 (their test solves the quadratic in fp64).  Depth limit 26: a stack of 28 levels is the deepest with
+    // which five workgroups share a CU's LDS (rt_wave.h, RT_WAVES_OBJ); the 5.2 M-triangle mesh came out deeper and ran at four.
+    bool all_triangles = true;
+    for (int i = 0; i < d->n_prims; i++) all_triangles &= d->prim_kind[i] == RT_PRIM_TRIANGLE;
+    int leaf_max = 4, depth_limit = 26; double c_prim = all_triangles ? 1.0 : 1.5;
     if (const char* e = std::getenv("RT_BVH_LEAF")) leaf_max = std::atoi(e);
     if (const char* e = std::getenv("RT_BVH_CPRIM")) c_prim = std::atof(e);
-    rtb::Tree tree = rtb::Builder(items, leaf_max, c_prim).build();
+    if (const char* e = std::getenv("RT_BVH_DEPTH")) depth_limit = std::max(8, std::atoi(e));
+    rtb::Tree tree = rtb::Builder(items, leaf_max, c_prim, depth_limit).build();
+    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] fast tree: %zu nodes, depth %d (limit %d), leaf_max %d, c_prim %.2f\n", tree.nodes.size(), tree.depth, depth_limit, leaf_max, c_prim);
     if (tree.depth + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode tree deeper than the traversal stack");
     if (tree.nodes.size() * sizeof(rt::BNode) >= (1ull << 32) || tree.order.size() * sizeof(rt::Prim<float>) >= (1ull << 32))
         return fail(RT_EUNSUPPORTED, "fast-mode tree or record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");

@@ -323,6 +323,28 @@ def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     osc.free()
 
 
+def test_depth_limited_tree_same_frame(R, golden_dir, monkeypatch):
+    """RT_BVH_DEPTH: the fast tree's depth limit (default 26, so that the traversal stack lets five workgroups share a CU's LDS;
+    a split whose larger side could not be finished within the limit is replaced by a median split).  The closest hit does not
+    depend on the tree, so a frame rendered over a tree squeezed to the minimum depth its size allows must match the default
+    tree's frame as the quantised twin does: ray and rejected-sample counts within 0.1 %, relative RMSE of the sums < 1 %."""
+    g, m = load(golden_dir, "obj")
+    osc = SCENES["obj"][1](golden_dir, m)
+    w, h = m["width"], m["height"]
+    n_tri = len(np.asarray(osc.export()["prim_kind"]))
+    tight = 1 + max(1, int(np.ceil(np.log2(max(n_tri, 8) / 4.0))) + 1)       # root level + halvings down to leaves of <= 4
+    frames = []
+    for depth in ("40", str(tight)):
+        monkeypatch.setenv("RT_BVH_DEPTH", depth)
+        sc = R.Scene(osc.export())
+        frames.append(sc.render_to_host(w, h, 0, 16, 12, R.MODE_FAST_FP32, seed=3))
+        sc.destroy()
+    (a, _, sa), (b, _, sb) = frames
+    assert abs(sa["rays"] - sb["rays"]) <= 1e-3 * sa["rays"] and abs(sa["rejected"] - sb["rejected"]) <= 1e-3 * sa["rejected"] + 2
+    assert np.sqrt(np.mean((a - b) ** 2)) <= 0.01 * np.sqrt(np.mean(a ** 2))
+    osc.free()
+
+
 @pytest.mark.parametrize("name", ["c0_seed1", "cornell", "smoke"])
 def test_converged_image_matches_cpu_reference_independent_streams(R, golden_dir, name):
     """The north-star image check: a converged GPU render against a converged CPU render of the same scene and spp drawn from
