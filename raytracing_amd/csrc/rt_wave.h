@@ -26,11 +26,12 @@ struct Trav {                 // per-lane traversal state, kept across phases
     vec3<float> idir, noid;   // 1/d and -o/d: a slab plane distance is one fma
     float slack;              // absolute slack of the slab comparison (rounding of o/d)
     float closest;
-    int32_t hit, cur, sp;
+    int32_t hit, cur;
+    uint32_t sp;              // LDS byte address of this lane's top stack entry (level * 1024 + lane * 4): push / pop are one add
     uint32_t rot;             // quantised nodes: per axis (byte a) 16 if the ray goes down the axis, else 0
 };
 
-__device__ inline void trav_begin(Trav& t, const Ray<float>& r)
+__device__ inline void trav_begin(Trav& t, const Ray<float>& r, uint32_t stack_base)
 {
     // a zero direction component would make 0 * inf = NaN in the slab test: nudge it (box tests only)
     auto safe = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; };
@@ -42,7 +43,7 @@ __device__ inline void trav_begin(Trav& t, const Ray<float>& r)
     t.closest = rt_inf<float>();
     t.hit = -1;
     t.cur = 0;
-    t.sp = 0;
+    t.sp = stack_base;
 }
 
 __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, float& t_near, bool& hit)
@@ -102,12 +103,16 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     }
     else { tile_x = (int) (blockIdx.x % (unsigned) tiles_x); tile_y = (int) (blockIdx.x / (unsigned) tiles_x); }
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* stack = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;       // entry `level` of this lane: stack[level * 256]
+    // entry `level` of this lane: LDS address of smem + level * 1024 + lane * 4, kept as a 32-bit LDS address so that a push or
+    // pop is one add and a ds instruction (no base to add, no generic pointer)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t stack_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) smem + threadIdx.x * 4u;
+    auto stack_at = [&](uint32_t lds_address) -> lds_u32& { return *(lds_u32*) (uintptr_t) lds_address; };
     float* tile_sum = reinterpret_cast<float*>(smem + a.lds_tile_offset);
     unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
     tile_sum[threadIdx.x * 3] = 0.f; tile_sum[threadIdx.x * 3 + 1] = 0.f; tile_sum[threadIdx.x * 3 + 2] = 0.f;
     if (threadIdx.x == 0) *item_counter = 0u;
-    stack[0] = (uint32_t) RT_BVH_SENTINEL;
+    stack_at(stack_base) = (uint32_t) RT_BVH_SENTINEL;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     Ray<float> ray;
     vec3<float> beta;      // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
                            // :215), so the only non-zero term of L = sum beta_i * emission_i is the last hit's
-    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = 0; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
+    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
 
     unsigned long long census[3] = { 0, 0, 0 };
     unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // diagnostic: wave time per phase (regenerate, nodes, leaves, shade)
@@ -165,7 +170,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                         depth = a.max_depth;
                         poisoned = false;
                         alive = true;
-                        trav_begin(tv, ray);
+                        trav_begin(tv, ray, stack_base);
                     }
                 }
             }
@@ -208,12 +213,12 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                         const bool left_first = tl <= tr;
                         const int32_t far = left_first ? c_right : c_left;
                         tv.cur = left_first ? c_left : c_right;
-                        tv.sp++;
-                        stack[tv.sp * 256] = (uint32_t) far;
+                        tv.sp += 1024u;
+                        stack_at(tv.sp) = (uint32_t) far;
                     }
                     else if (hl) tv.cur = c_left;
                     else if (hr) tv.cur = c_right;
-                    else { tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--; }
+                    else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
                 }
             }
             lap(1);
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
                     if (prim_t<float, kFull>(rec, sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
                 }
-                tv.cur = (int32_t) stack[tv.sp * 256]; tv.sp--;
+                tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
             }
             lap(2);
         }
@@ -287,7 +292,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            else trav_begin(tv, ray);
+            else trav_begin(tv, ray, stack_base);
         }
         lap(3);
     }
