@@ -412,14 +412,16 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
     if constexpr (sizeof(R) == sizeof(float)) {
         if (p.id == r.from && p.kind() != RT_PRIM_BOX && p.kind() != RT_PRIM_VOLUME) {   // (a box is tested again, without the side the ray starts on: see box_t;
                                                                                           //  a path scattered inside a medium is still inside it)
-            if (p.kind() == RT_PRIM_SPHERE) return sphere_from_surface(vec3<float>(p.g[0], p.g[1], p.g[2]), r, t_min, t_max, t);
-            if (p.kind() == RT_PRIM_MSPHERE) return sphere_from_surface(msphere_center(p, r.time), r, t_min, t_max, t);
-            return false;
+            if (p.kind() != RT_PRIM_SPHERE && p.kind() != RT_PRIM_MSPHERE) return false;
+            return sphere_from_surface(p.kind() == RT_PRIM_SPHERE ? vec3<float>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time), r, t_min, t_max, t);
         }
     }
     switch (p.kind()) {
-    case RT_PRIM_SPHERE: return sphere_t(vec3<R>(p.g[0], p.g[1], p.g[2]), p.g[3], r, t_min, t_max, t);
-    case RT_PRIM_MSPHERE: return sphere_t(msphere_center(p, r.time), p.g[8], r, t_min, t_max, t);
+    case RT_PRIM_SPHERE:                // one body for both sphere kinds: a wave whose leaves hold both would otherwise run the solve twice
+    case RT_PRIM_MSPHERE: {
+        const bool moving = p.kind() == RT_PRIM_MSPHERE;
+        return sphere_t(moving ? msphere_center(p, r.time) : vec3<R>(p.g[0], p.g[1], p.g[2]), moving ? p.g[8] : p.g[3], r, t_min, t_max, t);
+    }
     case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
     case RT_PRIM_BOX: if constexpr (kFull == 1 || kFull == 2) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
     case RT_PRIM_VOLUME: if constexpr (kFull == 1 || kFull == 2) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
