@@ -251,10 +251,10 @@ def main():
                   "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1),
                   "l1_peak_GBs": round(PEAK_L1_GBS, 0), "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4),
                   "node_record_bytes": node_bytes,
-                  "binding_limit": "vector L1 line-lookup rate: a divergent 16-B load costs one cache-line lookup per ACTIVE lane per clock per CU "
-                                   "(tools/ta_mask_bench.hip: 150 G random 64-B records/s chip-wide whatever the lane mask), so every node visit "
-                                   "costs 4 lookups per lane (2 with 32-B nodes) and idle lanes cost nothing; PMC TA_TA_BUSY 72-80 %, VALU 47-54 % "
-                                   "busy on the mesh with 64-B nodes (53 % / 68 % with 32-B nodes)"}
+                  "binding_limit": "mesh workload (32-B nodes, 5 waves/SIMD): VALU issue -- PMC VALU 92 % busy, TA_TA_BUSY 63 %; ~60 instructions "
+                                   "per node step at ~50 % lane utilisation.  With 64-B nodes the vector L1's line-lookup rate bound first (a divergent "
+                                   "16-B load costs one cache-line lookup per ACTIVE lane per clock per CU, tools/ta_mask_bench.hip: 150 G random 64-B "
+                                   "records/s chip-wide whatever the lane mask; TA 72-80 %, VALU 47-54 %).  Sphere scenes: VALU 86 % busy"}
         if scene_mb > 32.0:
             # node + primitive records do not fit the 8 x 4 MiB L2s: every visit is a record fetch from beyond L2
             # (Infinity Cache / HBM).  achieved = algorithmic record bytes (tests per ray from the kernel's own counters x
