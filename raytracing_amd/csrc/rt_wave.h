@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     const Prim<float>* __restrict__ fprims = sc.fprims;
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
 
-    uint32_t lane_rays = 0, lane_rejected = 0;     // per lane (32 bits are plenty: a lane's share of one tile), widened for the reduction
+    unsigned long long wave_rays = 0, wave_rejected = 0;   // wave-uniform (scalar registers): counted with a ballot at points where the wave has reconverged
     VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
 
     bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
@@ -242,8 +242,10 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
         }
 
         // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
-        if (alive && tv.cur == RT_BVH_SENTINEL) {
-            lane_rays++;
+        const bool shading = alive && tv.cur == RT_BVH_SENTINEL;
+        wave_rays += (unsigned long long) __popcll(__ballot(shading));
+        bool rejected_now = false;
+        if (shading) {
             const int path_rays = a.max_depth - depth + 1;               // this path's segments so far, this one included
             vec3<float> L;
             if (kCount && first_active_lane()) vs.w_bounce++;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
             if (done) {
                 alive = false;
                 bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
-                if (bad) lane_rejected++;
+                rejected_now = bad;
                 if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<float>(float(path_rays), bad ? 1.f : 0.f, 0.f); bad = false; }
                 if (!bad) {
                     float* dst = tile_sum + local * 3;
@@ -294,6 +296,7 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
             }
             else trav_begin(tv, ray, stack_base);
         }
+        wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
         lap(3);
     }
 
@@ -308,15 +311,9 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     }
 
     // wave-level reduction of the counters, one atomic pair per wave
-    unsigned long long n_rays = lane_rays, n_rejected = lane_rejected;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_rays += __shfl_down(n_rays, off, 64);
-        n_rejected += __shfl_down(n_rejected, off, 64);
-    }
     if (lane == 0) {
-        atomicAdd(&counters[0], n_rays);
-        if (n_rejected) atomicAdd(&counters[1], n_rejected);
+        atomicAdd(&counters[0], wave_rays);
+        if (wave_rejected) atomicAdd(&counters[1], wave_rejected);
     }
     if (kCount) {
         unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce;
