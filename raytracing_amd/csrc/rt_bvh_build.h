@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace rtb {
@@ -41,8 +42,8 @@ public:
     // depth_limit: no leaf deeper than this (the traversal stack lives in LDS and its size decides how many workgroups share a
     // CU).  A split whose larger side could not be finished within the limit even by halving is replaced by a median split, so the
     // limit holds whenever 1 + balanced_height(n) <= depth_limit; otherwise the builder falls back to RT_BUILD_SAH_DEPTH.
-    Builder(std::vector<Item>& items, int max_leaf, double cost_prim, int depth_limit = RT_BUILD_SAH_DEPTH)
-        : it(items), leaf_max(std::max(1, std::min(max_leaf, 8))), c_prim(cost_prim), limit(depth_limit)
+    Builder(std::vector<Item>& items, int max_leaf, double cost_prim, int depth_limit = RT_BUILD_SAH_DEPTH, int bins = 16)
+        : it(items), leaf_max(std::max(1, std::min(max_leaf, 8))), c_prim(cost_prim), limit(depth_limit), kBins(std::max(4, std::min((int) kMaxBins, bins)))
     {
         if (1 + balanced_height((int) items.size()) > limit) limit = std::max(limit, (int) RT_BUILD_SAH_DEPTH);
     }
@@ -84,7 +85,8 @@ private:
     double c_prim;
     int limit;
     Tree* tree = nullptr;
-    static const int kBins = 16;
+    static const int kMaxBins = 128;
+    int kBins;
 
     int32_t make_leaf(int b, int e)
     {
@@ -108,13 +110,13 @@ private:
             for (int axis = 0; axis < 3; axis++) {
                 double ext = cb.hi[axis] - cb.lo[axis];
                 if (!(ext > 0)) continue;
-                Box bb[kBins]; int cnt[kBins] = { 0 };
+                Box bb[kMaxBins]; int cnt[kMaxBins] = { 0 };
                 double scale = kBins / ext;
                 for (int i = b; i < e; i++) {
                     int k = std::min(kBins - 1, std::max(0, (int) ((it[i].c[axis] - cb.lo[axis]) * scale)));
                     cnt[k]++; bb[k].grow(it[i].box);
                 }
-                double right_area[kBins]; int right_cnt[kBins];
+                double right_area[kMaxBins]; int right_cnt[kMaxBins];
                 Box acc; int c = 0;
                 for (int k = kBins - 1; k > 0; k--) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.area(); right_cnt[k] = c; }
                 Box lacc; int lc = 0;
