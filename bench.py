@@ -251,7 +251,7 @@ def main():
                   "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1),
                   "l1_peak_GBs": round(PEAK_L1_GBS, 0), "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4),
                   "node_record_bytes": node_bytes,
-                  "binding_limit": "mesh workload (32-B nodes, 5 waves/SIMD): VALU issue -- PMC VALU 80 % busy, TA_TA_BUSY 71 % (profiles/r01_k_pmc_*); ~60 instructions "
+                  "binding_limit": "mesh workload (32-B nodes, 5 waves/SIMD): VALU issue -- PMC VALU 80 % busy, TA_TA_BUSY 69 % (profiles/r01_m_pmc_*); ~60 instructions "
                                    "per node step at ~50 % lane utilisation.  With 64-B nodes the vector L1's line-lookup rate bound first (a divergent "
                                    "16-B load costs one cache-line lookup per ACTIVE lane per clock per CU, tools/ta_mask_bench.hip: 150 G random 64-B "
                                    "records/s chip-wide whatever the lane mask; TA 72-80 %, VALU 47-54 %).  Sphere scenes: VALU 86 % busy"}

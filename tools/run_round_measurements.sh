@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r01k
+O=$GRAFT_REPO_ROOT/gpurun_out/r01m
 mkdir -p $O
 timeout -k 10 500 python -u -m pytest tests -x -q -m gpu --timeout 120 --timeout-method thread > $O/pytest_gpu.txt 2>&1 || { tail -20 $O/pytest_gpu.txt; exit 1; }
 tail -2 $O/pytest_gpu.txt
