@@ -1,0 +1,61 @@
+// tests/bvh_builder_check.cpp -- host-side check of the fast mode's SAH builder (raytracing_amd/csrc/rt_bvh_build.h), built and run by
+// tests/test_bvh_builder.py.  usage: bvh_builder_check <n_items> <depth_limit> <bins> <leaf_max> ; prints one line of key=value pairs.
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+#include <vector>
+
+#include "rt_bvh_build.h"
+
+int main(int argc, char** argv)
+{
+    if (argc < 5) return 2;
+    const int n = std::atoi(argv[1]), limit = std::atoi(argv[2]), bins = std::atoi(argv[3]), leaf_max = std::atoi(argv[4]);
+    std::mt19937 g(7);
+    std::uniform_real_distribution<double> u(0, 1);
+    std::vector<rtb::Item> items(n);
+    for (int i = 0; i < n; i++) {   // clustered, anisotropic boxes; a few duplicates of one centroid (the builder's median fallback)
+        double c[3] = { u(g) * u(g) * u(g) * 40 - 5, u(g) * 3, u(g) * u(g) * 10 };
+        if (i % 97 == 0) c[0] = c[1] = c[2] = 1.25;
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = c[k] - 0.02 * u(g); hi[k] = c[k] + 0.02 * u(g) * (k == 1 ? 5 : 1); }
+        items[i].box.grow(lo); items[i].box.grow(hi);
+        for (int k = 0; k < 3; k++) items[i].c[k] = c[k];
+        items[i].id = i;
+    }
+    const std::vector<rtb::Item> original = items;
+    rtb::Tree t = rtb::Builder(items, leaf_max, 1.0, limit, bins).build();
+
+    std::vector<int> seen_prim(n, 0), seen_node(t.nodes.size(), 0);
+    long bad_box = 0, bad_leaf = 0, shared = 0;
+    int max_depth = 0;
+    auto inside = [](const rtb::Box& outer, const rtb::Box& inner) {
+        for (int k = 0; k < 3; k++) if (inner.lo[k] < outer.lo[k] || inner.hi[k] > outer.hi[k]) return false;
+        return true;
+    };
+    // returns the bounds of the subtree under child code c, checking the box the parent stores for it
+    std::function<rtb::Box(int32_t, int)> walk = [&](int32_t c, int depth) {
+        rtb::Box b;
+        if (depth > max_depth) max_depth = depth;
+        if (c < 0) {
+            const int code = ~c, first = code >> 3, count = (code & 7) + 1;
+            if (count > leaf_max) bad_leaf++;
+            for (int k = 0; k < count; k++) { const int id = t.order[first + k]; seen_prim[id]++; b.grow(original[id].box); }
+            return b;
+        }
+        if (seen_node[c]++) { shared++; return b; }
+        const rtb::Node& nd = t.nodes[c];
+        const rtb::Box l = walk(nd.left, depth + 1), r = walk(nd.right, depth + 1);
+        if (!inside(nd.lbox, l) || !inside(nd.rbox, r)) bad_box++;
+        b.grow(nd.lbox); b.grow(nd.rbox);
+        return b;
+    };
+    if (!t.nodes.empty()) walk(0, 1);
+    long missing = 0, repeated = 0, unreachable = 0;
+    for (int v : seen_prim) { missing += v == 0; repeated += v > 1; }
+    for (int v : seen_node) unreachable += v == 0;
+    std::printf("n=%d nodes=%zu depth=%d walked_depth=%d missing=%ld repeated=%ld unreachable=%ld shared=%ld bad_box=%ld bad_leaf=%ld\n", n, t.nodes.size(),
+                t.depth, max_depth, missing, repeated, unreachable, shared, bad_box, bad_leaf);
+    return 0;
+}

@@ -1,0 +1,44 @@
+"""Host-side SAH builder of the fast mode (raytracing_amd/csrc/rt_bvh_build.h; no reference counterpart -- the reference's builder,
+bvh.hpp:22-56, stays resident for the parity modes and is checked in test_host_mirror.py).  The header is plain C++: a small
+harness (tests/bvh_builder_check.cpp) is compiled with g++ and walks the finished tree."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "raytracing_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bvh") / "bvh_builder_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", CSRC, "-o", exe, os.path.join(HERE, "bvh_builder_check.cpp")])
+    return exe
+
+
+def run(exe, n, limit, bins, leaf_max):
+    out = subprocess.check_output([exe, str(n), str(limit), str(bins), str(leaf_max)], text=True)
+    return {k: int(v) for k, v in (kv.split("=") for kv in out.split())}
+
+
+@pytest.mark.parametrize("n,limit,bins,leaf_max", [(1, 26, 16, 4), (2, 26, 16, 4), (5, 26, 64, 4), (1000, 26, 16, 4), (200000, 26, 64, 4),
+                                                   (200000, 18, 64, 4), (200000, 17, 16, 8), (50000, 40, 16, 1)])
+def test_tree_is_a_partition_with_containing_boxes_within_the_depth_limit(harness, n, limit, bins, leaf_max):
+    """Every primitive sits in exactly one leaf, every node is reached once, every box a parent stores contains what hangs below
+    it, leaves hold at most leaf_max records, the depth the builder reports is the depth of the deepest leaf, and it respects the
+    limit whenever halving could (1 + ceil(log2(n / leaf_max)) levels) -- down to the tightest limit that allows."""
+    r = run(harness, n, limit, bins, leaf_max)
+    assert r["missing"] == 0 and r["repeated"] == (1 if n == 1 else 0)       # a single primitive hangs under both children of its root
+    assert r["unreachable"] == 0 and r["shared"] == 0 and r["bad_box"] == 0 and r["bad_leaf"] == 0
+    if n > leaf_max:
+        assert r["depth"] == r["walked_depth"]          # root at level 1, a leaf one below the node that names it
+    else:
+        assert r["walked_depth"] - 1 <= r["depth"] <= r["walked_depth"]     # the one-node wrappers report the root's level
+    assert r["depth"] <= limit, r
+
+
+def test_impossible_limit_falls_back_to_the_stack_maximum(harness):
+    r = run(harness, 200000, 10, 16, 4)        # 2^10 leaves of 4 cannot hold 200 000 primitives
+    assert r["missing"] == 0 and r["repeated"] == 0 and r["bad_box"] == 0
+    assert 10 < r["depth"] <= 42
