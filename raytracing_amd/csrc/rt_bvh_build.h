@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace rtb {
@@ -169,5 +170,35 @@ private:
 public:
     static const int RT_BUILD_SAH_DEPTH = 40;   // below this depth fall back to median splits: bounds the traversal stack
 };
+
+// One axis of a 32-byte quantised node (rt_device.h QNode, decoded in rt_wave.h slab_quant): lo[c] / hi[c] are the two children's
+// planes, already padded by the kernel's fp32 decode error.  word = a float origin <= both lo whose low byte is the signed exponent e
+// of the step 2^e (the kernel uses the whole dword as the origin, so the origin must stay below the boxes whatever that byte
+// holds); q = bytes left lo, right lo, left hi, right hi in steps from the origin, lo rounded down and hi up.
+inline void quantise_axis(const double lo[2], const double hi[2], uint32_t& word, uint32_t& q)
+{
+    const double mn = std::min(lo[0], lo[1]), mx = std::max(hi[0], hi[1]);
+    // origin: a float <= mn whatever its low byte holds (the kernel reads the exponent byte as part of the origin).  Setting
+    // low bits moves a negative float down and a positive one up, so a positive origin starts one 256-ulp step lower.
+    float f = (float) mn; if ((double) f > mn) f = std::nextafterf(f, -INFINITY);
+    uint32_t bits; std::memcpy(&bits, &f, 4);
+    if (bits & 0x80000000u) { if (bits & 0xffu) bits = (bits | 0xffu) + 1u; }       // negative: magnitude up to the next multiple of 256 ulp
+    else if (bits >= 0x200u) bits = (bits & ~0xffu) - 0x100u;
+    else bits = 0x80000100u;                                                       // at zero: a tiny negative origin
+    auto as_float = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return (double) v; };
+    const double lowest = (bits & 0x80000000u) ? as_float(bits | 0xffu) : as_float(bits);
+    const double ext = std::max(mx - lowest, 0.0);
+    int e = (int) std::ceil(std::log2(std::max(ext / 254.0, 1e-37)));
+    while (std::ldexp(254.0, e) < ext) e++;
+    e = std::min(127, std::max(-126, e));
+    word = bits | (uint32_t) (e & 0xff);
+    const double origin = as_float(word), step = std::ldexp(1.0, e);
+    q = 0;
+    for (int c = 0; c < 2; c++) {   // bytes: left lo, right lo, left hi, right hi
+        const double ql = std::floor((lo[c] - origin) / step), qh = std::ceil((hi[c] - origin) / step);
+        const uint32_t l8 = (uint32_t) std::min(255.0, std::max(0.0, ql)), h8 = (uint32_t) std::min(255.0, std::max(0.0, qh));
+        q |= (l8 << (8 * c)) | (h8 << (16 + 8 * c));
+    }
+}
 
 }  // namespace rtb

@@ -326,28 +326,8 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         const rt::BNode& n = nodes[i];
         for (int a = 0; a < 3; a++) {
             const double lo[2] = { (double) n.lb[a] - pad, (double) n.rb[a] - pad }, hi[2] = { (double) n.lb[3 + a] + pad, (double) n.rb[3 + a] + pad };
-            const double mn = std::min(lo[0], lo[1]), mx = std::max(hi[0], hi[1]);
-            // origin: a float <= mn whatever its low byte holds (the kernel reads the exponent byte as part of the origin).  Setting
-            // low bits moves a negative float down and a positive one up, so a positive origin starts one 256-ulp step lower.
-            float f = down(mn);
-            uint32_t bits; std::memcpy(&bits, &f, 4);
-            if (bits & 0x80000000u) { if (bits & 0xffu) bits = (bits | 0xffu) + 1u; }       // negative: magnitude up to the next multiple of 256 ulp
-            else if (bits >= 0x200u) bits = (bits & ~0xffu) - 0x100u;
-            else bits = 0x80000100u;                                                       // at zero: a tiny negative origin
-            auto as_float = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return (double) v; };
-            const double lowest = (bits & 0x80000000u) ? as_float(bits | 0xffu) : as_float(bits);
-            const double ext = std::max(mx - lowest, 0.0);
-            int e = (int) std::ceil(std::log2(std::max(ext / 254.0, 1e-37)));
-            while (std::ldexp(254.0, e) < ext) e++;
-            e = std::min(127, std::max(-126, e));
-            const uint32_t word = bits | (uint32_t) (e & 0xff);
-            const double origin = as_float(word), step = std::ldexp(1.0, e);
-            uint32_t q = 0;
-            for (int c = 0; c < 2; c++) {   // bytes: left lo, right lo, left hi, right hi
-                const double ql = std::floor((lo[c] - origin) / step), qh = std::ceil((hi[c] - origin) / step);
-                const uint32_t l8 = (uint32_t) std::min(255.0, std::max(0.0, ql)), h8 = (uint32_t) std::min(255.0, std::max(0.0, qh));
-                q |= (l8 << (8 * c)) | (h8 << (16 + 8 * c));
-            }
+            uint32_t word, q;
+            rtb::quantise_axis(lo, hi, word, q);
             qn[i].o[a] = word;
             qn[i].q[a] = q;
         }

@@ -42,3 +42,15 @@ def test_impossible_limit_falls_back_to_the_stack_maximum(harness):
     r = run(harness, 200000, 10, 16, 4)        # 2^10 leaves of 4 cannot hold 200 000 primitives
     assert r["missing"] == 0 and r["repeated"] == 0 and r["bad_box"] == 0
     assert 10 < r["depth"] <= 42
+
+
+def test_quantised_axis_contains_its_boxes(tmp_path):
+    """rtb::quantise_axis, the encoder of the 32-byte nodes: over magnitudes 0 ... 1e12, box sizes 0 ... 1e4, both signs, boxes that
+    straddle zero and degenerate ones, the planes the kernel decodes (whole dword as the origin -- exponent byte included -- plus a
+    byte offset times 2^e) contain both children's planes, lo <= hi byte-wise (what lets a ray pick the near plane by the sign of
+    its direction alone), no plane is clipped at 255, and none is looser than one step beyond what the origin's low byte gives away."""
+    exe = str(tmp_path / "qnode_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", CSRC, "-o", exe, os.path.join(HERE, "qnode_check.cpp")])
+    r = {k: int(v) for k, v in (kv.split("=") for kv in subprocess.check_output([exe], text=True).split())}
+    assert r["cases"] > 30000
+    assert r["not_contained"] == 0 and r["disordered"] == 0 and r["clipped"] == 0 and r["loose"] == 0, r
