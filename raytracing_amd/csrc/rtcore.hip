@@ -126,8 +126,11 @@ int validate(const rt_scene_desc* d)
                 return fail(RT_EINVAL, "a box carries its wrappers in its own record, a volume takes none: prim_xform must be -1");
         }
     }
-    for (int i = 0; i < d->n_lights; i++)
+    for (int i = 0; i < d->n_lights; i++) {
         if (d->light_kind[i] < RT_PRIM_SPHERE || d->light_kind[i] > RT_PRIM_BOX) return fail(RT_EINVAL, "unknown light kind (a volume cannot be a light)");
+        if (d->light_mat && (d->light_mat[i] < 0 || d->light_mat[i] >= d->n_mats)) return fail(RT_EINVAL, "light material index out of range");
+    }
+    if (d->n_pixel_bytes >= (1ull << 32)) return fail(RT_EUNSUPPORTED, "tex_pixels beyond 4 GiB (texel offsets are 32-bit on the device)");
     for (int i = 0; i < d->n_mats; i++) {
         int k = d->mat_kind[i], t = d->mat_tex[i];
         if (k < RT_MAT_LAMBERTIAN || k > RT_MAT_FOG) return fail(RT_EINVAL, "unknown material kind");
@@ -138,11 +141,17 @@ int validate(const rt_scene_desc* d)
         int k = d->tex_kind[i];
         const double* td = d->tex_data + (size_t) i * RT_TEX_STRIDE;
         if (k == RT_TEX_CHECKER) {
-            if (td[0] < 0 || td[0] >= d->n_tex || td[1] < 0 || td[1] >= d->n_tex) return fail(RT_EINVAL, "checker texture index out of range");
+            // !(x >= 0 && x < n) also catches NaN; a fractional value would truncate to some other texture
+            for (int k = 0; k < 2; k++)
+                if (!(td[k] >= 0 && td[k] < d->n_tex) || td[k] != std::floor(td[k])) return fail(RT_EINVAL, "checker texture index out of range or not an integer");
         }
         else if (k == RT_TEX_IMAGE) {
             double w = td[0], h = td[1], ch = td[2], off = td[4];
-            if (w > 0 && (h <= 0 || ch < 3 || off < 0 || off + w * h * ch > (double) d->n_pixel_bytes || !d->tex_pixels))
+            // 1 or 2 channels (a grey PNG as stb hands it over): the reference reads base[0..2] whatever `channels` is (texture.hpp:115-122),
+            // i.e. the texel and its right-hand neighbours; so does the device, over a pool padded so the last texel's read stays inside
+            if (w > 0 && !(ch >= 1 && ch <= 4 && ch == std::floor(ch))) return fail(RT_EINVAL, "image texture: 1..4 channels expected");
+            if (w > 0 && (!(h > 0) || !(off >= 0) || w != std::floor(w) || h != std::floor(h) || off != std::floor(off) ||
+                          off + w * h * ch > (double) d->n_pixel_bytes || !d->tex_pixels))
                 return fail(RT_EINVAL, "image texture exceeds tex_pixels");
         }
         else if (k != RT_TEX_CONSTANT) return fail(RT_EINVAL, "unknown texture kind");
@@ -392,6 +401,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         for (int k = 0; k < 3; k++) xforms[i].t[k] = (xforms[i].flags & RT_PRIM_FLAG_TRANSLATE) ? (R) x[2 + k] : R(0);
     }
     std::vector<uint8_t> pixels(d->tex_pixels ? d->tex_pixels : nullptr, d->tex_pixels ? d->tex_pixels + d->n_pixel_bytes : nullptr);
+    pixels.insert(pixels.end(), 4, (uint8_t) 0);    // a 1- or 2-channel image's last texel is read as three bytes (validate())
 
     rt::Scene<R>& v = out.view;
     int rc;
@@ -539,6 +549,8 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     if (p->y_begin < 0 || p->y_end > p->height || p->y_begin > p->y_end) return fail(RT_EINVAL, "row range outside the image");
     if (p->spp_begin < 0 || p->spp_end < p->spp_begin) return fail(RT_EINVAL, "bad sample range");
     if (p->max_depth < 0) return fail(RT_EINVAL, "max_depth < 0");
+    if ((long long) p->spp_end - p->spp_begin >= (1 << 23)) return fail(RT_EINVAL, "more than 2^23 - 1 samples per pixel in one call (a tile's items are counted in 32 bits): split the range");
+    if ((p->flags & RT_FLAG_WAVEFRONT) && p->max_depth > 65535) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT keeps the depth in 16 bits: max_depth <= 65535");
     if ((long long) p->width * p->height >= (1LL << 31) / 3) return fail(RT_EINVAL, "image too large");
     if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32 && p->mode != RT_MODE_FP32_REFERENCE_TREE) return fail(RT_EINVAL, "unknown mode");
     if (s->n_lights <= 0)
@@ -711,6 +723,10 @@ int rt_scene_desc_save(const rt_scene_desc* d, const char* path)
     const char zeros[8] = { 0 };
     for (int i = 0; i < kCacheArrays && ok; i++) {
         if (a[i].bytes && a[i].src) ok = std::fwrite(a[i].src, 1, a[i].bytes, f) == a[i].bytes;
+        else if (a[i].bytes && a[i].src == nullptr && i == 15) {        // light_mat is optional (rt_scene_create reads a NULL one as zeros): so it is here
+            const std::vector<char> z(a[i].bytes, 0);
+            ok = std::fwrite(z.data(), 1, z.size(), f) == z.size();
+        }
         else if (a[i].bytes) { std::fclose(f); return fail(RT_EINVAL, "a required array of the scene description is NULL"); }
         const size_t padding = pad8(a[i].bytes) - a[i].bytes;
         if (ok && padding) ok = std::fwrite(zeros, 1, padding, f) == padding;

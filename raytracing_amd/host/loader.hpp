@@ -34,8 +34,10 @@ public:
     }
     group meshes() { return grp; }
     group* lights() { return lgt; }
+    int skipped_faces() const { return n_bad_faces; }      // faces dropped because an index pointed outside the vertex arrays
 
 private:
+    int n_bad_faces = 0;
     struct corner { int v, vt, vn; };
     group grp;
     group* lgt = new group();
@@ -107,6 +109,7 @@ private:
             else if (key == "f") {
                 std::vector<corner> face;
                 std::string tok;
+                bool bad_index = false;
                 while (ss >> tok) {
                     corner c = { 0, 0, 0 };
                     int field = 0;
@@ -118,9 +121,15 @@ private:
                             field++; start = i + 1;
                         }
                     }
+                    const bool has_vt = c.vt != 0, has_vn = c.vn != 0;
                     c.v = fix_index(c.v, pos.size() / 3); c.vt = fix_index(c.vt, tex.size() / 2); c.vn = fix_index(c.vn, nrm.size() / 3);
+                    // tinyobj fails the whole parse on an index it cannot resolve ("Failed parse `f' line"); here the face is dropped, so that a
+                    // malformed or truncated file can never index outside pos / tex / nrm
+                    if (c.v < 0 || (size_t) c.v >= pos.size() / 3 || (has_vt && (c.vt < 0 || (size_t) c.vt >= tex.size() / 2)) ||
+                        (has_vn && (c.vn < 0 || (size_t) c.vn >= nrm.size() / 3))) bad_index = true;
                     face.push_back(c);
                 }
+                if (bad_index) { n_bad_faces++; std::printf("[OBJLoader] face with an index outside the vertex arrays skipped: %s\n", line.c_str()); continue; }
                 if (face.size() < 3) continue;
                 std::vector<corner> tris;
                 if (face.size() == 4) {

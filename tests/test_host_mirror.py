@@ -133,3 +133,22 @@ def test_png_roundtrip(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "raytracing_amd", "host"), str(src), "-o", str(exe),
                     "-L", os.path.join(root, "raytracing_amd"), "-lrtcore", "-lz", "-Wl,-rpath," + os.path.join(root, "raytracing_amd")], check=True)
     assert subprocess.run([str(exe), str(tmp_path / "a.png")], capture_output=True, text=True).stdout.strip() == "ok"
+
+
+def test_obj_loader_drops_faces_with_indices_outside_the_arrays(tmp_path):
+    """A malformed or truncated OBJ (index 0, an index past the arrays, a relative index before their start) must not read outside the
+    vertex arrays: such faces are dropped (tinyobj fails the parse on them), the good ones load, and a file with no usable face is
+    an error through rth_last_error rather than a crash."""
+    mtl = tmp_path / "m.mtl"
+    mtl.write_text("newmtl a\nKd 0.5 0.5 0.5\nnewmtl l\nKe 3 3 3\n")
+    good = "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvn 0 0 1\nusemtl a\nf 1 2 3\nusemtl l\nf 2/1/1 4/1/1 3/1/1\nusemtl a\n"
+    bad_faces = ["f 0 0 0", "f 1 2 99", "f -9 1 2", "f 1/7 2/1 3/1", "f 1//5 2//1 3//1", "f 1 2 3 4 77"]
+    p = tmp_path / "bad.obj"
+    p.write_text(good + "\n".join(bad_faces) + "\n")
+    hs = HostScene.obj(str(p), 16, 16, 1)
+    assert int(hs.desc.contents.n_prims) == 2 and int(hs.desc.contents.n_lights) == 1
+    hs.free()
+    q = tmp_path / "allbad.obj"
+    q.write_text("mtllib m.mtl\nv 0 0 0\nusemtl a\n" + "\n".join(bad_faces) + "\n")
+    with pytest.raises(Exception, match="no triangles"):
+        HostScene.obj(str(q), 16, 16, 1)
