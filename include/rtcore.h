@@ -164,6 +164,16 @@ int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int sp
 int rt_first_hit(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
                  uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);
 
+/* rt_first_hit for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernel and bit-identical outputs; the device-side
+ * staging of rays and results (88 bytes per ray) lives in a static device array of the library (RT_NOALLOC_MAX_RAYS rays = 2.75 MiB
+ * per GPU the library runs on, held until the process ends) instead of hipMalloc'd memory: the call allocates and frees nothing.
+ * More than RT_NOALLOC_MAX_RAYS rays -> RT_EINVAL.  The scene's device must be the current one.  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (two host threads) race; serialise them. */
+#define RT_NOALLOC_MAX_RAYS 32768
+int rt_first_hit_noalloc(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
+                         uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);
+
 /* Closest hit of the same rays through RT_MODE_FAST_FP32's tree (fp32): primitive id or -1, and t.  No counterpart in
  * the reference; lets tests check that the fast tree returns the reference's hits. */
 int rt_first_hit_fast(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, float* t);

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -66,6 +67,34 @@ template <> double box_hi<double>(double v) { return v; }
 template <> float box_lo<float>(double v) { return down(v); }   // fp32 boxes contain the fp64 boxes
 template <> float box_hi<float>(double v) { return up(v); }
 
+}  // namespace
+
+// ---- rt_first_hit_noalloc: device-side staging that lives in the code object instead of in hipMalloc'd memory.
+// Layout: n rays x 7 doubles, then the six output arrays in rt_first_hit's order of decreasing alignment (t, hash, prim, front,
+// n_box, n_leaf).  In host code the array's NAME is only a handle for hipGetSymbolAddress: the address a kernel may use is the
+// one that call returns, per device (every GPU the library runs on holds its own copy of the array until the process ends).
+#define RT_NOALLOC_BYTES_PER_RAY (7 * 8 + 8 + 8 + 4 + 4 + 4 + 4)
+static __device__ __align__(256) unsigned char scratch[(size_t) RT_NOALLOC_MAX_RAYS * RT_NOALLOC_BYTES_PER_RAY];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = { nullptr };
+
+// device address of `scratch` on the CURRENT device, resolved once per device
+int scratch_address(int device, void** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RT_EUNSUPPORTED, "device index beyond the library's per-device table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(RT_EHIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
 }  // namespace
 
 struct rt_scene {
@@ -646,6 +675,42 @@ int rt_first_hit(rt_scene* s, const double* rays, size_t n, int32_t* prim, doubl
     if (rc == RT_OK && visit_hash) chk(hipMemcpy(visit_hash, d_hash, n * 8, hipMemcpyDeviceToHost), "download");
     (void) hipFree(d_rays); (void) hipFree(d_out);
     return rc;
+}
+
+int rt_first_hit_noalloc(rt_scene* s, const double* rays, size_t n, int32_t* prim, double* t, int32_t* front, uint32_t* n_box, uint32_t* n_leaf,
+                         uint64_t* visit_hash)
+{
+    if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
+    if (n > (size_t) RT_NOALLOC_MAX_RAYS)
+        return fail(RT_EINVAL, "rt_first_hit_noalloc: at most RT_NOALLOC_MAX_RAYS (" + std::to_string(RT_NOALLOC_MAX_RAYS) + ") rays per call, got " + std::to_string(n) +
+                                   "; split the batch or use rt_first_hit");
+    if (n == 0) return RT_OK;
+    int device = -1;
+    HIP_TRY(hipGetDevice(&device));
+    if (device != s->device) return fail(RT_EINVAL, "the scene lives on another device than the current one");
+    void* base = nullptr;
+    int rc = scratch_address(device, &base);
+    if (rc) return rc;
+    // every byte a call reads it has written first (rays by the upload, outputs by the kernel for all idx < n): nothing to clear
+    char* b = static_cast<char*>(base);
+    double* d_rays = reinterpret_cast<double*>(b);
+    char* o = b + n * 7 * sizeof(double);
+    double* d_t = reinterpret_cast<double*>(o);
+    unsigned long long* d_hash = reinterpret_cast<unsigned long long*>(o + n * 8);
+    int32_t* d_prim = reinterpret_cast<int32_t*>(o + n * 16);
+    int32_t* d_front = reinterpret_cast<int32_t*>(o + n * 20);
+    uint32_t* d_box = reinterpret_cast<uint32_t*>(o + n * 24);
+    uint32_t* d_leaf = reinterpret_cast<uint32_t*>(o + n * 28);
+    HIP_TRY(hipMemcpy(d_rays, rays, n * 7 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(rt::launch_first_hit(s->d64.view, d_rays, (int) n, d_prim, d_t, d_front, d_box, d_leaf, d_hash, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (prim) HIP_TRY(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, d_t, n * 8, hipMemcpyDeviceToHost));
+    if (front) HIP_TRY(hipMemcpy(front, d_front, n * 4, hipMemcpyDeviceToHost));
+    if (n_box) HIP_TRY(hipMemcpy(n_box, d_box, n * 4, hipMemcpyDeviceToHost));
+    if (n_leaf) HIP_TRY(hipMemcpy(n_leaf, d_leaf, n * 4, hipMemcpyDeviceToHost));
+    if (visit_hash) HIP_TRY(hipMemcpy(visit_hash, d_hash, n * 8, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_first_hit_fast(rt_scene* s, const double* rays, size_t n, int32_t* prim, float* t)

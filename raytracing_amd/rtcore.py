@@ -13,8 +13,9 @@ LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(HERE, "librtcore.so")   
 MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE = 0, 1, 2
 FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_LEGACY_LOOP, FLAG_WAVEFRONT = 1, 2, 4, 8, 16, 32
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
+NOALLOC_MAX_RAYS = 32768
 
-EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_fast", "rt_buffer_alloc", "rt_buffer_free",
+EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_buffer_alloc", "rt_buffer_free",
            "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
            "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
@@ -68,6 +69,7 @@ def load_library():
         L.rt_resolve.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_first_hit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.rt_first_hit_noalloc.argtypes = L.rt_first_hit.argtypes
         L.rt_first_hit_fast.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.rt_buffer_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.rt_buffer_free.argtypes = [C.c_void_p]
@@ -161,12 +163,14 @@ class Scene:
             load_library().rt_scene_destroy(self.h)
             self.h = None
 
-    def first_hit(self, rays):
+    def first_hit(self, rays, noalloc=False):
+        """noalloc: through rt_first_hit_noalloc (staging in the library's static device array, at most NOALLOC_MAX_RAYS rays)"""
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
         n = len(rays)
         out = dict(prim=np.zeros(n, np.int32), t=np.zeros(n), front=np.zeros(n, np.int32), nbox=np.zeros(n, np.uint32),
                    nleaf=np.zeros(n, np.uint32), hash=np.zeros(n, np.uint64))
-        _check(load_library().rt_first_hit(self.h, _ptr(rays, C.c_double), n, _ptr(out["prim"], C.c_int32), _ptr(out["t"], C.c_double),
+        fn = load_library().rt_first_hit_noalloc if noalloc else load_library().rt_first_hit
+        _check(fn(self.h, _ptr(rays, C.c_double), n, _ptr(out["prim"], C.c_int32), _ptr(out["t"], C.c_double),
                                            _ptr(out["front"], C.c_int32), _ptr(out["nbox"], C.c_uint32), _ptr(out["nleaf"], C.c_uint32),
                                            _ptr(out["hash"], C.c_uint64)))
         return out
