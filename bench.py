@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A *step* is one pass of the hot path over one frame: every rank renders its share of the frame's samples with the
-HIP kernels (rt_render), the per-rank fp32 accumulation buffers are summed onto rank 0 by an RCCL reduce over xGMI,
+HIP kernels (rt_render), the per-rank accumulation buffers are summed onto rank 0 by an RCCL reduce over xGMI,
 and rank 0 resolves the frame (mean, gamma, clamp, 8-bit).  The samples of the frame are split over the ranks
 (spp split; RNG streams are keyed by the GLOBAL sample index, so the image does not depend on N): total work is
 fixed as N grows => "scaling": "strong".
@@ -15,14 +15,22 @@ OBJ loader of the C++ host mirror, reference BVH builder, 3840x2160, 1024 spp, m
 random_spheres` runs configs[1] instead: the reference's random_scene() (~485 spheres) + the documented area light.
 Rays are counted by the kernel: trace() invocations that traverse the scene (raytracing.cpp:32-37).
 
+Precision: the default mode is RT_MODE_FAST_FP64 -- the reference's arithmetic (fp64, its evaluation order) for rays, primitive
+tests, shading and sums, behind the library's SAH tree whose boxes only cull (dtype "f64": the reference computes in fp64).
+`--mode fp32` is the fp32 fast mode; at N=1 its rate on the same frame is reported next to the headline as `fp32_mode`.
+
 The one JSON line also carries
-  roofline      the render kernel against the chip's peaks: algorithmic work per launch / HIP-event duration;
+  roofline      the render kernel against the roof that binds it (VALU issue; frac <= 1 by construction), plus the vector-L1 and HBM
+                fractions: algorithmic work per launch / HIP-event duration measured in this run;
+  image         the timed scene at reduced resolution: GPU vs the CPU oracle on the same streams (rel. RMSE, PSNR) and converged
+                (independent streams) against the CPU-vs-CPU noise floor;
   cpu_reference (extra) the unmodified reference binary oracle/_ref/ref_harness, one thread, bounded sample; absent if not built
   cpu_baseline  the oracle (CPU restatement of the reference, fp64) timed on this box's host cores on a bounded
                 sample of the same workload -- a reported baseline, not the target.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -31,13 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic cost model of the dominant kernel (DESIGN.md "Measurement"): per box test 6 fma + 6 min/max + 4 = 22 flop
-# (fma = 2) and half a 64-B node record; per leaf test ~40 flop (triangle: 2 cross, 4 dot, 1 rcp; sphere: 3 dots, disc, sqrt,
-# div) and one 48-B primitive record; per ray ~150 flop of shading/sampling/regeneration.
+# (fma = 2) and half a node record; per leaf test ~40 flop (triangle: 2 cross, 4 dot, 1 rcp; sphere: 3 dots, disc, sqrt,
+# div) and one primitive record; per ray ~150 flop of shading/sampling/regeneration.  Box tests are fp32 in every fast mode;
+# leaf tests and shading are fp64 in the fp64 modes.
 FLOP_BOX, FLOP_LEAF, FLOP_SHADE = 24.0, 40.0, 150.0
-BYTES_LEAF = 48.0   # fast tree: one node record (64 B, or 32 B quantised) per two box tests, one 48-B record per leaf test
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector fp32 peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP64_TFLOPS = 78.6      # vector fp64
 PEAK_HBM_GBS = 8000.0
-PEAK_L1_GBS = 256 * 64 * 2.4   # vector L1 (TCP) -> register path: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s; the unit that binds the node loop
+PEAK_L1_GBS = 256 * 64 * 2.4   # vector L1 (TCP) -> register path: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s
+
+MODES = {"fp64": "MODE_FAST_FP64", "fp32": "MODE_FAST_FP32", "fp32ref": "MODE_FP32_REFERENCE_TREE", "fp64ref": "MODE_REFERENCE_FP64"}
 
 
 def parse():
@@ -49,7 +60,12 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (split over the ranks)")
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--mode", choices=["fp32", "fp32ref", "fp64"], default="fp32", help="fp32: fast SAH tree; fp32ref: reference tree in fp32; fp64: reference mode")
+    ap.add_argument("--mode", choices=list(MODES), default="fp64",
+                    help="fp64: fast SAH tree, fp64 results (the reference's precision; default); fp32: fast tree in fp32; fp32ref: reference tree in fp32; "
+                         "fp64ref: reference tree and visit order in fp64 (the bit-exact parity mode)")
+    ap.add_argument("--no-fp32", action="store_true", help="N=1: skip the extra fp32-mode timing of the same frame")
+    ap.add_argument("--image-width", type=int, default=240, help="width of the reduced-resolution image check (same aspect, 0 = skip)")
+    ap.add_argument("--image-spp", type=int, default=256, help="spp of the converged (independent streams) image check")
     ap.add_argument("--workload", choices=["obj", "random_spheres", "soup"], default="obj", help="obj: BASELINE configs[2] (the config the metric is quoted on); random_spheres: configs[1]; soup: configs[3] (triangle soup with image textures)")
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
     ap.add_argument("--soup-tex", type=int, default=1024, help="edge of each of the 64 map_Kd textures")
@@ -61,23 +77,62 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, host_arrays):
-    """Oracle (kind 'port': CPU restatement of the reference, pinned bit-exact to it by tests/golden) on the host cores.
-    Bounded sample: the same scene (re-created from the host mirror's flattened arrays), resolution and depth at
-    --cpu-spp samples per pixel."""
+def oracle_scene(args, host_arrays):
+    """The CPU oracle's scene for this workload (tests/oracle_lib.py over oracle/librt_oracle.so; checker and baseline only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = min(16, os.cpu_count() or 1)
     # random_spheres: the oracle's own builder (nested bvh over shutter [0,1], as the reference builds it); OBJ: static
     # triangles re-created from the flattened arrays
-    s = O.Scene.c0(args.width, args.height, 1) if args.workload == "random_spheres" else O.scene_from_arrays(host_arrays, 1)
+    return O, (O.Scene.c0(args.width, args.height, 1) if args.workload == "random_spheres" else O.scene_from_arrays(host_arrays, 1))
+
+
+def cpu_baseline(args, O, s):
+    """Oracle (kind 'port': CPU restatement of the reference, pinned bit-exact to it by tests/golden) on the host cores.
+    Bounded sample: the same scene, resolution and depth at --cpu-spp samples per pixel."""
+    cores = min(16, os.cpu_count() or 1)
     t0 = time.perf_counter()
     _, _, cnt = s.render(0, args.cpu_spp, args.depth, O.RNG_COUNTER, seed=1, n_threads=cores, want_rgb=False)
     dt = time.perf_counter() - t0
-    s.free()
     return {"value": round(int(cnt[0]) / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{args.workload} {args.width}x{args.height}, {args.cpu_spp} spp, max_depth {args.depth}: "
                       f"{int(cnt[0])} rays in {dt:.2f} s (fp64, reference tree, OpenMP over rows, per-(pixel,sample) RNG streams)"}
+
+
+def image_check(args, R, O, s, scene, mode):
+    """The metric's second half ("image RMSE"): the TIMED scene at reduced resolution (same aspect, same depth), GPU against the CPU
+    oracle.  (1) same streams, 16 spp: every sample draws the same numbers on both sides, so the difference is the arithmetic's;
+    (2) converged, independent streams (different seeds) at --image-spp: GPU-vs-CPU relative RMSE next to the CPU-vs-CPU RMSE of two
+    seeds, the Monte-Carlo noise floor at that spp.  Relative RMSE = rms(diff of mean linear radiance) / rms(CPU radiance); PSNR on
+    the 8-bit images."""
+    import numpy as np
+    w = args.image_width
+    h = max(2, round(w * args.height / args.width))
+    s.set_size(w, h)
+    cores = min(16, os.cpu_count() or 1)
+
+    def psnr(x, y):
+        mse = float(np.mean((x.astype(np.float64) - y.astype(np.float64)) ** 2))
+        return None if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 2)
+
+    def rel(x, y, spp):
+        return float(np.sqrt(np.mean((x - y) ** 2)) / max(np.sqrt(np.mean(y ** 2)), 1e-300))
+
+    spp_same = 16
+    cpu, cpu_rgb, cnt = s.render(0, spp_same, args.depth, O.RNG_COUNTER, seed=1, n_threads=cores)
+    gpu, gpu_rgb, st = scene.render_to_host(w, h, 0, spp_same, args.depth, mode, seed=1)
+    out = {"width": w, "height": h, "max_depth": args.depth,
+           "same_streams": {"spp": spp_same, "rel_rmse": float(f"{rel(gpu.astype(np.float64), cpu, spp_same):.3e}"), "psnr_8bit_dB": psnr(gpu_rgb, cpu_rgb),
+                            "psnr_note": "null = the 8-bit images are identical", "rays_gpu": st["rays"], "rays_cpu": int(cnt[0])}}
+    spp = args.image_spp
+    if spp > 0:
+        a, a_rgb, _ = s.render(0, spp, args.depth, O.RNG_COUNTER, seed=101, n_threads=cores)
+        b, b_rgb, _ = s.render(0, spp, args.depth, O.RNG_COUNTER, seed=202, n_threads=cores)
+        c, c_rgb, _ = scene.render_to_host(w, h, 0, spp, args.depth, mode, seed=303)
+        out["converged"] = {"spp": spp, "rel_rmse_gpu_vs_cpu": round(rel(c.astype(np.float64), a, spp), 4), "rel_rmse_cpu_vs_cpu": round(rel(b, a, spp), 4),
+                            "psnr_gpu_vs_cpu_dB": psnr(c_rgb, a_rgb), "psnr_cpu_vs_cpu_dB": psnr(b_rgb, a_rgb),
+                            "tolerance": "rel_rmse_gpu_vs_cpu <= 1.25 x rel_rmse_cpu_vs_cpu (the noise floor); PSNR within 1 dB of the CPU-vs-CPU PSNR"}
+    s.set_size(args.width, args.height)
+    return out
 
 
 def cpu_reference(args, obj_path):
@@ -141,8 +196,9 @@ def main():
             dist.init_process_group(backend)
 
     w, h, spp = args.width, args.height, args.spp
-    mode = {"fp32": R.MODE_FAST_FP32, "fp32ref": R.MODE_FP32_REFERENCE_TREE, "fp64": R.MODE_REFERENCE_FP64}[args.mode]
-    dtype = torch.float64 if args.mode == "fp64" else torch.float32
+    mode = getattr(R, MODES[args.mode])
+    is_fp64 = args.mode in ("fp64", "fp64ref")
+    dtype = torch.float64 if is_fp64 else torch.float32
     # the host mirror prints the reference's "[INFO] building bvh..." lines on stdout; keep stdout for the JSON line
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -175,15 +231,20 @@ def main():
     # this rank's share of the frame's samples
     k0, k1 = sample_range(rank, world, spp) if args.split == "spp" else (0, spp)
     y0, y1 = (0, h) if args.split == "spp" else row_range(rank, world, h)     # rows split: the other rows of `accum` stay zero, the reduce gathers
-    accum = torch.zeros((h, w, 3), dtype=dtype, device="cuda")
+    accum = torch.zeros((h, w, 3), dtype=dtype, device="cuda")        # rows split: the rows of other ranks stay zero, the reduce gathers
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        st = scene.render(accum.data_ptr(), w, h, k0, k1, args.depth, mode, seed=1, stream=stream, y_begin=y0, y_end=y1)   # syncs, returns kernel stats
-        reduce_frame(accum, world, dst=0)
+    def step(step_mode=mode, buf=None):
+        buf = accum if buf is None else buf
+        if args.split == "rows" and world > 1:
+            # rows mode: a rank's buffer is zero outside its rows, so the SUM reduce is a gather.  Rank 0's other rows hold the last step's
+            # reduced frame: clear them (render overwrites [y0, y1) itself)
+            buf[:y0].zero_(); buf[y1:].zero_()
+        st = scene.render(buf.data_ptr(), w, h, k0, k1, args.depth, step_mode, seed=1, stream=stream, y_begin=y0, y_end=y1)   # syncs, returns kernel stats
+        reduce_frame(buf, world, dst=0)
         if rank == 0:
-            R.resolve(accum.data_ptr(), args.mode == "fp64", w * h, spp, rgb.data_ptr(), stream=stream)
+            R.resolve(buf.data_ptr(), buf.dtype == torch.float64, w * h, spp, rgb.data_ptr(), stream=stream)
         return st
 
     def fence():
@@ -219,66 +280,93 @@ def main():
         probe = scene.render(accum.data_ptr(), w, h, k0, k0 + 1, args.depth, mode, seed=1, stream=stream, flags=R.FLAG_COUNT_TESTS, y_begin=y0, y_end=y1)
         box_per_ray = probe["box_tests"] / max(probe["rays"], 1)
         leaf_per_ray = probe["leaf_tests"] / max(probe["rays"], 1)
+        zero_share = probe["zero_direction_rays"] / max(probe["rays"], 1)
         rays_per_launch = rays / max(args.steps, 1)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        flop_per_ray = box_per_ray * FLOP_BOX + leaf_per_ray * FLOP_LEAF + FLOP_SHADE
+        secs = avg_ms * 1e-3
+        fast = args.mode in ("fp64", "fp32")
+        # flops by precision: box tests are fp32 in the fast modes; leaf tests and shading are in the mode's result precision
+        flop32 = box_per_ray * FLOP_BOX if (fast or not is_fp64) else 0.0
+        flop_res = leaf_per_ray * FLOP_LEAF + FLOP_SHADE + (0.0 if (fast or not is_fp64) else box_per_ray * FLOP_BOX)
+        if is_fp64:
+            flop64 = flop_res
+        else:
+            flop32, flop64 = flop32 + flop_res, 0.0
+        flop_per_ray = flop32 + flop64
+        achieved_tflops = rays_per_launch * flop_per_ray / secs / 1e12
+        # the VALU roof for THIS mix of fp32 and fp64 work: total flops / the time the mix takes at the two vector peaks
+        time_at_peak = rays_per_launch * (flop32 / (PEAK_FP32_TFLOPS * 1e12) + flop64 / (PEAK_FP64_TFLOPS * 1e12))
+        peak_mix = rays_per_launch * flop_per_ray / time_at_peak / 1e12
+        valu_frac = time_at_peak / secs
         # OBJ-loader scenes (triangles + phong only) walk the 32-byte quantised nodes by default (rtcore.hip, RT_QNODES overrides)
-        quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and args.mode == "fp32"
-        node_bytes = 32.0 if quantised else 64.0
-        bytes_per_ray = box_per_ray * node_bytes / 2 + leaf_per_ray * BYTES_LEAF
-        if args.mode == "fp64":
-            bytes_per_ray = box_per_ray * 56.0 + leaf_per_ray * 112.0
-        achieved_tflops = rays_per_launch * flop_per_ray / (avg_ms * 1e-3) / 1e12
-        fetch_gbs = rays_per_launch * bytes_per_ray / (avg_ms * 1e-3) / 1e9
-        peak = PEAK_FP32_TFLOPS if args.mode != "fp64" else PEAK_FP32_TFLOPS / 2
+        quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and fast
+        node_bytes = (32.0 if quantised else 64.0) if fast else (56.0 if is_fp64 else 32.0)
+        leaf_bytes = 96.0 if is_fp64 else 48.0
+        bytes_per_ray = (box_per_ray * node_bytes / 2 if fast else box_per_ray * node_bytes) + leaf_per_ray * leaf_bytes
+        fetch_gbs = rays_per_launch * bytes_per_ray / secs / 1e9
         d = host.desc.contents
-        scene_mb = (d.n_prims * node_bytes * 0.6 + d.n_prims * 48) / 1e6      # ~0.6 SAH nodes per primitive + 48 B primitive records
+        scene_mb = (d.n_prims * node_bytes * 0.6 + d.n_prims * leaf_bytes) / 1e6      # ~0.6 SAH nodes per primitive + primitive records
         # HBM-side bytes per launch: bytes per ray measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
-        # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload at reduced spp (profiles/hbm_traffic.json, written by
-        # tools/hbm_traffic.py), scaled by this launch's ray count; null when no measurement of this workload is on file
-        traffic = None
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload and mode at reduced spp (profiles/hbm_traffic.json, written by
+        # tools/hbm_traffic.py from a run of this same command under the profiler), scaled by this launch's ray count; null when no
+        # measurement of this workload and mode is on file.  A counter pass cannot run inside the timed run.
+        traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 rec = json.load(f).get(f"{args.workload}:{int(d.n_prims)}:{args.mode}:{w}x{h}:d{args.depth}")
             if rec:
                 traffic = int(rec["bytes_per_ray"] * rays_per_launch)
+                traffic_src = f"profiles/hbm_traffic.json: {rec['bytes_per_ray']:.1f} B/ray measured at {rec.get('spp_profiled')} spp ({rec.get('round', 'r01')}), x this launch's rays"
         except (OSError, ValueError):
             pass
-        kernel_name = {"fp32": "rt::render_wave_kernel", "fp32ref": "rt::render_kernel<float>", "fp64": "rt::render_kernel<double>"}[args.mode]
-        common = {"kernel": kernel_name, "traffic": traffic, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
-                  "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
-                  "flop_per_ray": round(flop_per_ray, 1), "scene_bytes_per_ray": round(bytes_per_ray, 1), "scene_MB": round(scene_mb, 1),
-                  "valu_TFLOPs": round(achieved_tflops, 3), "scene_fetch_GBs": round(fetch_gbs, 1),
-                  "l1_peak_GBs": round(PEAK_L1_GBS, 0), "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4),
-                  "node_record_bytes": node_bytes,
-                  "binding_limit": "mesh workload (32-B nodes, 5 waves/SIMD): VALU issue -- PMC VALU 80 % busy, TA_TA_BUSY 69 % (profiles/r01_m_pmc_*); ~60 instructions "
-                                   "per node step at ~50 % lane utilisation.  With 64-B nodes the vector L1's line-lookup rate bound first (a divergent "
-                                   "16-B load costs one cache-line lookup per ACTIVE lane per clock per CU, tools/ta_mask_bench.hip: 150 G random 64-B "
-                                   "records/s chip-wide whatever the lane mask; TA 72-80 %, VALU 47-54 %).  Sphere scenes: VALU 86 % busy"}
-        if scene_mb > 32.0:
-            # node + primitive records do not fit the 8 x 4 MiB L2s: every visit is a record fetch from beyond L2
-            # (Infinity Cache / HBM).  achieved = algorithmic record bytes (tests per ray from the kernel's own counters x
-            # record sizes) / kernel time, against the HBM peak.
-            roofline = dict(common, bound="hbm", achieved=round(fetch_gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(fetch_gbs / PEAK_HBM_GBS, 4),
-                            note="algorithmic bytes = box_tests/2 x node record (node_record_bytes) + leaf_tests x 48-B primitive record per ray; records are served by "
-                                 "L1/L2 + the 256 MiB Infinity Cache as well as HBM (traffic = memory-side bytes), so achieved can approach or "
-                                 "pass the HBM-only peak; the kernel's binding limits are VALU issue and the vector-memory address path, see valu_TFLOPs")
-        else:
-            roofline = dict(common, bound="valu", achieved=round(achieved_tflops, 3), peak=peak, unit="TFLOP/s", frac=round(achieved_tflops / peak, 4),
-                            note="scene fits L1/L2: no HBM stream to be bound by (HBM traffic = the frame buffer once per launch); "
-                                 "bound is VALU issue under wave64 divergence")
+        hbm_frac = round(traffic / secs / 1e9 / PEAK_HBM_GBS, 4) if traffic is not None else None
+        kernel_name = {"fp64": "rt::render_wave_kernel<double>", "fp32": "rt::render_wave_kernel<float>", "fp32ref": "rt::render_kernel<float>",
+                       "fp64ref": "rt::render_kernel<double>"}[args.mode]
+        assert 0.0 < valu_frac <= 1.0, f"roofline fraction {valu_frac} outside (0, 1]: the cost model or the peak is wrong"
+        roofline = {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": round(peak_mix, 1), "unit": "TFLOP/s", "frac": round(valu_frac, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "hbm_peak_GBs": PEAK_HBM_GBS,
+                    "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4), "l1_achieved_GBs": round(fetch_gbs, 1), "l1_peak_GBs": round(PEAK_L1_GBS, 0),
+                    "kernel": kernel_name, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
+                    "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
+                    "flop_per_ray": {"fp32": round(flop32, 1), "fp64": round(flop64, 1)}, "record_bytes_per_ray": round(bytes_per_ray, 1),
+                    "node_record_bytes": node_bytes, "leaf_record_bytes": leaf_bytes, "scene_MB": round(scene_mb, 1),
+                    "note": "No dense contraction (no MFMA) and no HBM stream: node and primitive records are served by L1/L2/Infinity Cache (hbm_frac = measured "
+                            "memory-side bytes / time / 8 TB/s).  The roof that binds is VALU issue under wave64 divergence: frac = algorithmic flops "
+                            "(24 per fp32 box test, 40 per leaf test, 150 per ray of shading; leaf + shading in the result precision) / kernel time, "
+                            "against the vector peaks 157.3 (fp32) / 78.6 (fp64) TFLOP/s weighted by this mix (`peak`).  l1_frac = algorithmic record "
+                            "bytes / time against the vector-L1 peak"}
         out = {
-            "metric": "Mrays/s (node), path-traced frame; image RMSE vs reference CPU checked in tests/", "value": round(total_rays / elapsed / 1e6, 2),
+            "metric": "Mrays/s (node), path-traced frame, results in the reference's precision; image RMSE vs the reference CPU path in `image`",
+            "value": round(total_rays / elapsed / 1e6, 2),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if args.mode == "fp64" else "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if is_fp64 else "f32",
             "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
-            "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth,
-                       "parallelism": f"{args.split} split over {world} GPU(s), RCCL reduce of the fp32 accumulation buffer" if world > 1 else "single GPU",
-                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims)},
+            "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth, "mode": MODES[args.mode].replace("MODE_", "RT_MODE_"),
+                       "parallelism": f"{args.split} split over {world} GPU(s), RCCL reduce of the accumulation buffer" if world > 1 else "single GPU",
+                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims),
+                       "zero_direction_ray_share": round(zero_share, 4),
+                       "zero_direction_note": "share of rays_per_step traced with direction (0,0,0): phong leaves wo unset (material.hpp:225-229,252-254), "
+                                              "the reference traces and counts such a ray (it misses everything); they cost a few node visits each"},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_fp32 and args.mode == "fp64":
+            # the same frame in the fp32 fast mode (results held to an RMSE bar instead of bit parity): one untimed + one timed step
+            acc32 = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            step(R.MODE_FAST_FP32, acc32)
+            fence()
+            t1 = time.perf_counter()
+            st32 = step(R.MODE_FAST_FP32, acc32)
+            fence()
+            dt32 = time.perf_counter() - t1
+            out["fp32_mode"] = {"value": round(st32["rays"] / dt32 / 1e6, 2), "unit": "Mrays/s", "dtype": "f32", "mode": "RT_MODE_FAST_FP32", "steps": 1,
+                                "ms_per_step": round(dt32 * 1e3, 3), "kernel_ms": round(st32["kernel_ms"], 3), "rays_per_step": st32["rays"]}
+            del acc32
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, host.arrays())
+            O, osc = oracle_scene(args, host.arrays())
+            out["cpu_baseline"] = cpu_baseline(args, O, osc)
+            if args.image_width > 0:
+                out["image"] = image_check(args, R, O, osc, scene, mode)
+            osc.free()
             ref = cpu_reference(args, obj_path if args.workload != "random_spheres" else None)
             if ref:
                 out["cpu_reference"] = ref      # extra to the contract: the unmodified reference next to the multi-threaded port

@@ -105,6 +105,14 @@ typedef struct rt_scene_desc {
 #define RT_MODE_FAST_FP32      1 /* fp32, the library's own SAH tree with ordered traversal (same closest hits, ~4x fewer
                                     tests than the reference tree); accumulation buffer is fp32 */
 #define RT_MODE_FP32_REFERENCE_TREE 2 /* fp32 arithmetic over the reference's tree in the reference's visit order (A/B baseline) */
+#define RT_MODE_FAST_FP64      3 /* the reference's arithmetic -- fp64, no FMA contraction, its evaluation order, for rays, primitive
+                                    tests, hit records, shading and sums -- behind the library's SAH tree: boxes only cull (fp32,
+                                    conservative), they never decide a hit, so closest hits, t bits and radiance are those of
+                                    RT_MODE_REFERENCE_FP64 except where two surfaces lie at the same t (the reference's visit order
+                                    picks one) and for volumes (their random draws follow the visit order).  accum_dev is double;
+                                    sums are added per tile in completion order, so they match the reference mode's to rounding
+                                    of the additions, not bit for bit.  Zero-direction rays (phong) against spheres
+                                    follow the reference's NaN slabs only in RT_MODE_REFERENCE_FP64. */
 
 #define RT_FLAG_ACCUMULATE 1     /* add this call's sample sums into accum_dev instead of overwriting it */
 #define RT_FLAG_EARLY_EXIT 2     /* stop a path as soon as its sample is known to be rejected (NaN/inf, raytracing.cpp:108-110).
@@ -138,6 +146,8 @@ typedef struct rt_render_stats {
     uint64_t wave_leaf_steps;    /* ... of the leaf-test loop */
     uint64_t wave_bounces;       /* ... of the bounce loop */
     uint64_t phase_ticks[4];     /* RT_FLAG_COUNT_TESTS, fast mode: wave time (100 MHz ticks, summed over waves) in the regenerate, node, leaf and shade phases */
+    uint64_t zero_direction_rays; /* RT_FLAG_COUNT_TESTS: of `rays`, those traced with direction (0,0,0): phong leaves `wo` unset (material.hpp:225-229,
+                                    252-254), the reference traces that ray all the same (it misses everything) and so counts it */
 } rt_render_stats;
 
 /* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit
@@ -148,7 +158,7 @@ int rt_scene_destroy(rt_scene* scene);
 /* Renders samples [spp_begin, spp_end) of rows [y_begin, y_end): per pixel the SUM over those samples of
  * trace(emit(x, y)) with rejected samples zeroed -- the body of the k-loop at raytracing.cpp:101-113.
  * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
- * double for RT_MODE_REFERENCE_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
+ * double for RT_MODE_REFERENCE_FP64 and RT_MODE_FAST_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
  * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats.  With RT_FLAG_WAVEFRONT the call
  * runs a loop of extend / shade kernels over a path pool (84 B per slot, RT_WF_SLOTS slots, default 2 Mi; allocated on the
  * scene's first such call, freed by rt_scene_destroy), polls a device flag and returns when the samples are done. */
@@ -177,6 +187,11 @@ int rt_first_hit_noalloc(rt_scene* scene, const double* rays, size_t n_rays, int
 /* Closest hit of the same rays through RT_MODE_FAST_FP32's tree (fp32): primitive id or -1, and t.  No counterpart in
  * the reference; lets tests check that the fast tree returns the reference's hits. */
 int rt_first_hit_fast(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, float* t);
+
+/* Closest hit of the same rays through the fast tree with the render kernels' own culling code: fp64 != 0 is RT_MODE_FAST_FP64's
+ * traversal (primitive, t bits and frontward flag must equal rt_first_hit's), fp64 == 0 RT_MODE_FAST_FP32's (t widened to double).
+ * Walks the 32-byte quantised nodes when the scene's renders do.  No counterpart in the reference.  Synchronous. */
+int rt_first_hit_tree(rt_scene* scene, const double* rays, size_t n_rays, int fp64, int32_t* prim, double* t, int32_t* front);
 
 /* Device-buffer helpers for hosts that do not otherwise touch HIP (the C++ driver). */
 int rt_buffer_alloc(size_t bytes, void** dev_out);

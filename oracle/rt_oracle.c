@@ -1058,6 +1058,10 @@ static void random_scene(orc_scene* s)
     s->n_objects = 1;
 }
 
+/* test / bench plumbing, no counterpart in the reference: another image size over the same scene and the same (already derived)
+ * camera fields -- the caller keeps the aspect ratio -- so one scene serves a full-size timing run and a small parity render */
+void orc_set_size(orc_scene* s, int width, int height) { s->width = width; s->height = height; }
+
 orc_scene* orc_build_c0(int width, int height, unsigned seed)
 {
     orc_scene* s = orc_scene_new(width, height, seed);

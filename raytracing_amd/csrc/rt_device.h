@@ -653,7 +653,7 @@ template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriSh
     return true;
 }
 
-struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; uint32_t w_node, w_leaf, w_bounce; };   // w_*: wave-level loop iterations (counted by the first active lane)
+struct VisitStats { uint32_t n_box, n_leaf; uint64_t hash; uint32_t w_node, w_leaf, w_bounce; uint32_t n_zero = 0; };   // n_zero: rays traced with an all-zero direction (phong's unset wo)   // w_*: wave-level loop iterations (counted by the first active lane)
 __device__ inline bool first_active_lane() { return (int) __lane_id() == __ffsll((unsigned long long) __ballot(1)) - 1; }
 
 // scene.objects.intersect(r, rec) (group.hpp:68-83 -> bvh.hpp:58-68) as a walk over the pre-order program.
@@ -1168,6 +1168,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
             n_rays++;
             path_rays++;
             if (kCount && first_active_lane()) vs.w_bounce++;
+            if (kCount && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) vs.n_zero++;
             R t;
             int prim;
             if constexpr (kTrav == 2) prim = closest_hit_bvh<kCount ? 1 : 0>(sc.bnodes, sc.fprims, sc.side(), ray, t, reinterpret_cast<uint32_t*>(smem) + threadIdx.x, &vs, &g);
@@ -1244,13 +1245,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
         if (n_rejected) atomicAdd(&counters[1], n_rejected);
     }
     if (kCount) {   // diagnostic launches only: per-lane 32-bit counts are ample for one launch's per-pixel work
-        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce;
+        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce, nz = vs.n_zero;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64);
+            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64); nz += __shfl_down(nz, off, 64);
             wn += __shfl_down(wn, off, 64); wl += __shfl_down(wl, off, 64); wb += __shfl_down(wb, off, 64);
         }
-        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); }
+        if (lane == 0) { atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); atomicAdd(&counters[7], nz); }
     }
 }
 

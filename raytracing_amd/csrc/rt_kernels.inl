@@ -3,11 +3,31 @@
 #include <cstddef>
 #include <vector>
 #include "rt_launch.h"
-#ifdef RT_WITH_FAST_BVH
+#ifdef RT_WITH_WAVE
 #include "rt_wave.h"
 #endif
 
 namespace rt {
+
+#ifdef RT_WITH_WAVE
+// one variant of the wave kernel (rt_wave.h); more than 48 KiB of dynamic LDS needs the attribute set once per kernel
+template <typename R, bool kQuant, int kFull>
+hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters)
+{
+    if (lds > 48 * 1024) {
+        static thread_local size_t configured = 0;
+        if (lds > configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, false, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, true, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+    }
+    if (count) hipLaunchKernelGGL((render_wave_kernel<R, true, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
+    else hipLaunchKernelGGL((render_wave_kernel<R, false, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_REAL* accum, unsigned long long* counters, hipStream_t s)
 {
@@ -16,16 +36,41 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
     dim3 grid((unsigned) (tiles_x * tiles_y)), block(256);
     const bool count = (a.flags & RT_FLAG_COUNT_TESTS) != 0;
-    // dynamic LDS = [traversal region: fast-mode stack | staged program | nothing] + [fp32 modes: tile sums + item counter]
-    const size_t tile_bytes = sizeof(RT_REAL) == sizeof(float) ? 768 * sizeof(float) + 16 : 0;
+    // dynamic LDS = [traversal region: fast-mode stack | staged program | nothing] + [workgroup-owned tiles: tile sums + item counter]
     size_t region = 0;
     int trav = 0;
-#ifdef RT_WITH_FAST_BVH
+#ifdef RT_WITH_WAVE
     if (a.bvh_stack_levels > 0) { trav = 2; region = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t); }
 #endif
     if (trav == 0 && a.lds_ops_bytes + a.lds_prims_bytes > 0) { trav = 1; region = (size_t) a.lds_ops_bytes + a.lds_prims_bytes; }
+    const size_t tile_bytes = (sizeof(RT_REAL) == sizeof(float) || trav == 2) ? 768 * sizeof(RT_REAL) + 16 : 0;
     a.lds_tile_offset = (uint32_t) region;
     const size_t lds = region + tile_bytes;
+#ifdef RT_WITH_WAVE
+    if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
+        if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64)); }
+        // variants by scene content (rt_device.h prim_t): 2 instances (unquantised nodes), 1 boxes or volumes, 3 an OBJ-loader scene, 0 the rest
+        if (a.kinds == 2) return launch_wave<RT_REAL, false, 2>(count, grid, lds, s, sc, a, accum, counters);
+        if (a.kinds == 1) return launch_wave<RT_REAL, false, 1>(count, grid, lds, s, sc, a, accum, counters);
+        if (a.kinds == 3) {
+            if (sizeof(RT_REAL) == sizeof(double)) {
+                if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
+                return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);
+            }
+#ifdef RT_WITH_FAST_BVH
+            // fp32: the lean variant runs RT_WAVES_OBJ workgroups per CU when their LDS fits (32-byte nodes are its default) ...
+            if (lds * RT_WAVES_OBJ <= 160 * 1024) {
+                if (a.quantised) return launch_wave<float, true, 3>(count, grid, lds, s, sc, a, accum, counters);
+                return launch_wave<float, false, 3>(count, grid, lds, s, sc, a, accum, counters);
+            }
+            // ... a deeper tree: the same code at the other variants' occupancy
+            if (!a.quantised) return launch_wave<float, false, 4>(count, grid, lds, s, sc, a, accum, counters);
+#endif
+        }
+        if (a.quantised) return launch_wave<RT_REAL, true, 0>(count, grid, lds, s, sc, a, accum, counters);
+        return launch_wave<RT_REAL, false, 0>(count, grid, lds, s, sc, a, accum, counters);
+    }
+#endif
     if (lds > 48 * 1024) {
         static thread_local size_t configured = 0;
         if (lds > configured) {
@@ -34,62 +79,19 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 #ifdef RT_WITH_FAST_BVH
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
             configured = lds;
         }
     }
 #ifdef RT_WITH_FAST_BVH
-    if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
-        if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64)); }
-        if (a.kinds == 2) {     // scenes with instances: the variant whose primitive tests look at the transforms (unquantised nodes)
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 2>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, false, 2>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (a.kinds == 3 && a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // OBJ-loader scene, 32-byte nodes (the default for it), RT_WAVES_OBJ workgroups share a CU's LDS
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, true, 3>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, true, 3>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (a.kinds == 3 && !a.quantised && lds * RT_WAVES_OBJ <= 160 * 1024) {   // ... with 64-byte nodes (RT_QNODES=0)
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 3>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, false, 3>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (a.kinds == 3 && !a.quantised) {   // ... a deeper tree: the same code at the other variants' occupancy
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 4>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, false, 4>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (a.kinds == 1) {   // boxes or volumes
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 1>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, false, 1>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (a.quantised) {
-            if (count) hipLaunchKernelGGL((render_wave_kernel<true, true, 0>), grid, block, lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave_kernel<false, true, 0>), grid, block, lds, s, sc, a, accum, counters);
-        }
-        else if (count) hipLaunchKernelGGL((render_wave_kernel<true, false, 0>), grid, block, lds, s, sc, a, accum, counters);
-        else hipLaunchKernelGGL((render_wave_kernel<false, false, 0>), grid, block, lds, s, sc, a, accum, counters);
-        return hipGetLastError();
-    }
     if (trav == 2) {
         if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 2, true>), grid, block, lds, s, sc, a, accum, counters);
         else hipLaunchKernelGGL((render_kernel<RT_REAL, 2, false>), grid, block, lds, s, sc, a, accum, counters);
         return hipGetLastError();
     }
 #endif
+    if (trav == 2) return hipErrorInvalidValue;      // fp64 over the fast tree has no lane-synchronous variant (rtcore.hip refuses the flag)
     if (trav == 1) {
         if (count) hipLaunchKernelGGL((render_kernel<RT_REAL, 1, true>), grid, block, lds, s, sc, a, accum, counters);
         else hipLaunchKernelGGL((render_kernel<RT_REAL, 1, false>), grid, block, lds, s, sc, a, accum, counters);
@@ -100,6 +102,22 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     }
     return hipGetLastError();
 }
+
+#ifdef RT_WITH_WAVE
+hipError_t launch_first_hit_tree(const Scene<RT_REAL>& sc, const double* rays, int n, int quantised, int32_t* prim, RT_REAL* t, int32_t* front, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const size_t stack_bytes = (size_t) (sc.bvh_depth + 2) * 256 * sizeof(uint32_t);
+    if (stack_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&first_hit_tree_kernel<RT_REAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) stack_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&first_hit_tree_kernel<RT_REAL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) stack_bytes);
+        if (e != hipSuccess) return e;
+    }
+    if (quantised) hipLaunchKernelGGL((first_hit_tree_kernel<RT_REAL, true>), dim3((n + 255) / 256), dim3(256), stack_bytes, s, sc, rays, n, prim, t, front);
+    else hipLaunchKernelGGL((first_hit_tree_kernel<RT_REAL, false>), dim3((n + 255) / 256), dim3(256), stack_bytes, s, sc, rays, n, prim, t, front);
+    return hipGetLastError();
+}
+#endif
 
 #ifdef RT_WITH_FAST_BVH
 hipError_t wf_extend_grid(int lds_levels, int* grid_out)

@@ -2,4 +2,5 @@
 // the reference's g++ -O3 x86-64 build ("fp64 vs fp32").
 #define RT_REAL double
 #define RT_WITH_FIRST_HIT 1
+#define RT_WITH_WAVE 1
 #include "rt_kernels.inl"

@@ -13,6 +13,10 @@ hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* acc
 struct WfBuffers { WfPool pool; uint32_t capacity; int bvh_depth; void* host_pinned; };
 hipError_t wf_extend_grid(int lds_levels, int* grid_out);
 hipError_t wf_render(const Scene<float>& sc, const RenderArgs& a, const WfBuffers& buf, float* accum, unsigned long long out[8], hipStream_t s);
+// closest hit of explicit rays through the fast tree with the wave kernel's own culling code (rt_wave.h): R = double is
+// RT_MODE_FAST_FP64's traversal, whose primitive, t bits and frontward flag must be the reference walk's
+hipError_t launch_first_hit_tree(const Scene<double>& sc, const double* rays, int n, int quantised, int32_t* prim, double* t, int32_t* front, hipStream_t s);
+hipError_t launch_first_hit_tree(const Scene<float>& sc, const double* rays, int n, int quantised, int32_t* prim, float* t, int32_t* front, hipStream_t s);
 hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int n, int32_t* prim, float* t, hipStream_t s);
 hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,
                             uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash, hipStream_t s);

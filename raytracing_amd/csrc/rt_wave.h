@@ -13,11 +13,20 @@
 //   shade      : lanes whose closest hit is known run the trace() body (raytracing.cpp:41-69) and either start the
 //                next segment's traversal or retire the sample into the LDS tile.
 // Same arithmetic, RNG streams and sample sums as the loop it replaces (order of the fp32 tile additions aside).
+//
+// The kernel is templated on the scalar R of everything that decides a RESULT -- rays, primitive tests, hit records, shading,
+// throughput, sums.  Box culling is fp32 for both: a box test only decides whether a sub-tree is looked at, never what is found in
+// it, and it is conservative (boxes rounded outward, slack on the comparison).  R = float is RT_MODE_FAST_FP32; R = double is
+// RT_MODE_FAST_FP64: the reference's own arithmetic (fp64, no FMA contraction, its evaluation order) behind the fast tree, so
+// closest hits, t bits and radiance are the reference mode's, at the cost of 96-byte leaf records and fp64 shading.
 #pragma once
 
 #include "rt_device.h"
 #ifndef RT_WAVES_OBJ
 #define RT_WAVES_OBJ 5    // waves per SIMD of the OBJ-loader variant (96 VGPRs): measured 4 waves +11 % time, 6 waves +4 %; the other variants lose at 5
+#endif
+#ifndef RT_WAVES_FP64
+#define RT_WAVES_FP64 2   // waves per SIMD of the R = double variants (256 registers)
 #endif
 
 namespace rt {
@@ -25,28 +34,43 @@ namespace rt {
 struct Trav {                 // per-lane traversal state, kept across phases
     vec3<float> idir, noid;   // 1/d and -o/d: a slab plane distance is one fma
     float slack;              // absolute slack of the slab comparison (rounding of o/d)
-    float closest;
+    float closest;            // far bound of the slab tests: the closest hit so far (R = double: rounded from Closest<double>::t)
     int32_t hit, cur;
     uint32_t sp;              // LDS byte address of this lane's top stack entry (level * 1024 + lane * 4): push / pop are one add
     uint32_t rot;             // quantised nodes: per axis (byte a) 16 if the ray goes down the axis, else 0
 };
+// the closest hit's distance in the precision of the results.  R = float: Trav::closest is that value already.
+template <typename R> struct Closest { R t; };
+template <> struct Closest<float> {};
+__device__ inline float closest_of(const Trav& t, const Closest<float>&) { return t.closest; }
+__device__ inline double closest_of(const Trav&, const Closest<double>& c) { return c.t; }
+__device__ inline void set_closest(Trav& t, Closest<float>&, float v) { t.closest = v; }
+__device__ inline void set_closest(Trav& t, Closest<double>& c, double v) { c.t = v; t.closest = (float) v; }   // the slab test's slack covers the rounding
 
-__device__ inline void trav_begin(Trav& t, const Ray<float>& r, uint32_t stack_base)
+// Slack of the slab comparison `near <= far * rel + slack_k * max|o/d|`.
+// fp32 rays: t = fma(plane, idir, -o*idir) rounds once; what is left is the rounding of o*idir itself (<= 1/2 ulp of it).
+// fp64 rays culled in fp32: 1/d comes from the rounded d through the hardware reciprocal (1 ulp), o is rounded, the far bound is the
+// rounded closest hit: each plane distance is off by <= ~2e-7 (|t| + 2 |o/d|); the constants below leave 5x that.
+template <typename R> struct cull_slack;
+template <> struct cull_slack<float> { static constexpr float rel = 1.0000004f, k = 2.4e-7f; };
+template <> struct cull_slack<double> { static constexpr float rel = 1.000002f, k = 2e-6f; };
+
+template <typename R> __device__ inline void trav_begin(Trav& t, Closest<R>& c, const Ray<R>& r, uint32_t stack_base)
 {
     // a zero direction component would make 0 * inf = NaN in the slab test: nudge it (box tests only)
     auto safe = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; };
-    t.idir = vec3<float>(1.0f / safe(r.d.x), 1.0f / safe(r.d.y), 1.0f / safe(r.d.z));
-    t.noid = vec3<float>(-r.o.x * t.idir.x, -r.o.y * t.idir.y, -r.o.z * t.idir.z);
-    // t = fma(plane, idir, -o*idir) rounds once; what is left is the rounding of o*idir itself (<= 1/2 ulp of it)
-    t.slack = 2.4e-7f * fmaxf(fmaxf(fabsf(t.noid.x), fabsf(t.noid.y)), fabsf(t.noid.z));
+    if constexpr (sizeof(R) == sizeof(float)) t.idir = vec3<float>(1.0f / safe(r.d.x), 1.0f / safe(r.d.y), 1.0f / safe(r.d.z));
+    else t.idir = vec3<float>(__builtin_amdgcn_rcpf(safe((float) r.d.x)), __builtin_amdgcn_rcpf(safe((float) r.d.y)), __builtin_amdgcn_rcpf(safe((float) r.d.z)));
+    t.noid = vec3<float>(-(float) r.o.x * t.idir.x, -(float) r.o.y * t.idir.y, -(float) r.o.z * t.idir.z);
+    t.slack = cull_slack<R>::k * fmaxf(fmaxf(fabsf(t.noid.x), fabsf(t.noid.y)), fabsf(t.noid.z));
     t.rot = (t.idir.x < 0.f ? 16u : 0u) | (t.idir.y < 0.f ? 16u << 8 : 0u) | (t.idir.z < 0.f ? 16u << 16 : 0u);
-    t.closest = rt_inf<float>();
+    set_closest(t, c, rt_inf<R>());
     t.hit = -1;
     t.cur = 0;
     t.sp = stack_base;
 }
 
-__device__ inline void slab_fma(const float* b, const Trav& t, float t_min, float& t_near, bool& hit)
+template <typename R> __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, float& t_near, bool& hit)
 {
     float x0 = fmaf(b[0], t.idir.x, t.noid.x), x1 = fmaf(b[3], t.idir.x, t.noid.x);
     float y0 = fmaf(b[1], t.idir.y, t.noid.y), y1 = fmaf(b[4], t.idir.y, t.noid.y);
@@ -54,7 +78,7 @@ __device__ inline void slab_fma(const float* b, const Trav& t, float t_min, floa
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t.closest));
     t_near = tn;
-    hit = tn <= fmaf(tf, 1.0000004f, t.slack);     // conservative under fp32 rounding
+    hit = tn <= fmaf(tf, cull_slack<R>::rel, t.slack);     // conservative under fp32 rounding
 }
 
 // record at a 32-bit byte offset from a wave-uniform base: one 32-bit multiply / shift and the scalar-base addressing mode instead
@@ -66,7 +90,7 @@ template <typename T> __device__ inline const T* at32(const T* base, uint32_t by
 
 // both children of a quantised node (rt_device.h QNode): per axis t = q * (step * idir) + (origin * idir - o * idir), near planes in
 // bytes 0-1 and far planes in bytes 2-3 once the dword is rotated for the ray's direction (Trav::rot)
-__device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
+template <typename R> __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
 {
     float ln[3], rn[3], lf[3], rf[3];
     const float idir[3] = { t.idir.x, t.idir.y, t.idir.z }, noid[3] = { t.noid.x, t.noid.y, t.noid.z };
@@ -79,12 +103,12 @@ __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, fl
     }
     const float tnl = fmaxf(fmaxf(ln[0], ln[1]), fmaxf(ln[2], t_min)), tfl = fminf(fminf(lf[0], lf[1]), fminf(lf[2], t.closest));
     const float tnr = fmaxf(fmaxf(rn[0], rn[1]), fmaxf(rn[2], t_min)), tfr = fminf(fminf(rf[0], rf[1]), fminf(rf[2], t.closest));
-    tl = tnl; hl = tnl <= fmaf(tfl, 1.0000004f, t.slack);
-    tr = tnr; hr = tnr <= fmaf(tfr, 1.0000004f, t.slack);
+    tl = tnl; hl = tnl <= fmaf(tfl, cull_slack<R>::rel, t.slack);
+    tr = tnr; hr = tnr <= fmaf(tfr, cull_slack<R>::rel, t.slack);
 }
 
-template <bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<float> sc, RenderArgs a, float* __restrict__ accum,
+template <typename R, bool kCount, bool kQuant, int kFull>
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? RT_WAVES_FP64 : kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut
@@ -108,9 +132,9 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t stack_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) smem + threadIdx.x * 4u;
     auto stack_at = [&](uint32_t lds_address) -> lds_u32& { return *(lds_u32*) (uintptr_t) lds_address; };
-    float* tile_sum = reinterpret_cast<float*>(smem + a.lds_tile_offset);
+    R* tile_sum = reinterpret_cast<R*>(smem + a.lds_tile_offset);
     unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
-    tile_sum[threadIdx.x * 3] = 0.f; tile_sum[threadIdx.x * 3 + 1] = 0.f; tile_sum[threadIdx.x * 3 + 2] = 0.f;
+    tile_sum[threadIdx.x * 3] = R(0); tile_sum[threadIdx.x * 3 + 1] = R(0); tile_sum[threadIdx.x * 3 + 2] = R(0);
     if (threadIdx.x == 0) *item_counter = 0u;
     stack_at(stack_base) = (uint32_t) RT_BVH_SENTINEL;
     __syncthreads();
@@ -122,21 +146,23 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
         ii = a.y_begin + tile_y * 16 + (wv >> 1) * 8 + (ln >> 3);
     };
     const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
-    const float t_min = consts<float>::tmin;
+    const float t_min = consts<float>::tmin;          // box culling; primitive tests take consts<R>::tmin
     const BNode* __restrict__ nodes = sc.bnodes;
-    const Prim<float>* __restrict__ fprims = sc.fprims;
+    const Prim<R>* __restrict__ fprims = sc.fprims;
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
 
     unsigned long long wave_rays = 0, wave_rejected = 0;   // wave-uniform (scalar registers): counted with a ballot at points where the wave has reconverged
-    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0;
+    VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0; vs.n_zero = 0;
 
     bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
     int depth = 0, local = 0;
     Rng g; g.s = 0;
-    Ray<float> ray;
-    vec3<float> beta;      // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
+    Ray<R> ray;
+    vec3<R> beta;          // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
                            // :215), so the only non-zero term of L = sum beta_i * emission_i is the last hit's
     Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
+    Closest<R> best;
+    if constexpr (sizeof(R) == 8) best.t = R(0);
 
     unsigned long long census[3] = { 0, 0, 0 };
     unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // diagnostic: wave time per phase (regenerate, nodes, leaves, shade)
@@ -163,14 +189,14 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     pixel_of(local, j, i);
                     if (j < a.width && i < a.y_end) {                                         // else: slot outside the image (edge tiles)
                         g.seed(a.seed, (uint32_t) (i * a.width + j), (uint32_t) k);
-                        float x = (float(j) + uniform<float>(g)) / float(a.width - 1);         // raytracing.cpp:102-103
-                        float y = (float(i) + uniform<float>(g)) / float(a.height - 1);
+                        R x = (R(j) + uniform<R>(g)) / R(a.width - 1);                          // raytracing.cpp:102-103
+                        R y = (R(i) + uniform<R>(g)) / R(a.height - 1);
                         ray = camera_emit(sc.cam, g, x, y);
-                        beta = vec3<float>(1.f, 1.f, 1.f);
+                        beta = vec3<R>(R(1), R(1), R(1));
                         depth = a.max_depth;
                         poisoned = false;
                         alive = true;
-                        trav_begin(tv, ray, stack_base);
+                        trav_begin(tv, best, ray, stack_base);
                     }
                 }
             }
@@ -198,13 +224,13 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                     int32_t c_left, c_right;
                     if (kQuant) {
                         const QNode n = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
-                        slab_quant(n, tv, t_min, tl, hl, tr, hr);
+                        slab_quant<R>(n, tv, t_min, tl, hl, tr, hr);
                         c_left = n.left; c_right = n.right;
                     }
                     else {
                         const BNode n = *at32(nodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
-                        slab_fma(n.lb, tv, t_min, tl, hl);
-                        slab_fma(n.rb, tv, t_min, tr, hr);
+                        slab_fma<R>(n.lb, tv, t_min, tl, hl);
+                        slab_fma<R>(n.rb, tv, t_min, tr, hr);
                         c_left = n.left; c_right = n.right;
                     }
                     if (kCount && first_active_lane()) vs.w_node++;
@@ -226,15 +252,15 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
             if (tv.cur < 0 && tv.cur != RT_BVH_SENTINEL) {
                 const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
                 for (int k = 0; k < count; k++) {
-                    float t;
+                    R t;
                     if (kCount && first_active_lane()) vs.w_leaf++;
                     if (kCount) vs.n_leaf++;
                     // the whole 48-byte record in one round trip (three 16-byte loads issued together): left to itself the compiler
                     // sinks each field's load into the branch that first needs it -- id, then the edges, then the vertex: three
                     // dependent memory latencies per triangle (mesh workload -4.6 % time, leaf share of the wave time 21 -> 13 %)
-                    Prim<float> rec = *at32(fprims, (uint32_t) (first + k) * (uint32_t) sizeof(Prim<float>));
+                    Prim<R> rec = *at32(fprims, (uint32_t) (first + k) * (uint32_t) sizeof(Prim<R>));
                     asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
-                    if (prim_t<float, kFull>(rec, sc.side(), ray, t_min, tv.closest, t, &g)) { tv.closest = t; tv.hit = first + k; }
+                    if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, &g)) { set_closest(tv, best, t); tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
             }
@@ -244,34 +270,35 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
         // ---------------------------------------------------------------- shade: trace() body for lanes whose hit is known
         const bool shading = alive && tv.cur == RT_BVH_SENTINEL;
         wave_rays += (unsigned long long) __popcll(__ballot(shading));
+        if (kCount && shading && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) vs.n_zero++;
         bool rejected_now = false;
         if (shading) {
             const int path_rays = a.max_depth - depth + 1;               // this path's segments so far, this one included
-            vec3<float> L;
+            vec3<R> L;
             if (kCount && first_active_lane()) vs.w_bounce++;
             bool done = true;
             if (tv.hit >= 0) {
-                Hit<float> h;
-                fill_record<float, kFull>(fprims[tv.hit], sc.side(), ray, tv.closest, sc.need_uv != 0, h);
-                const Mat<float>& m = sc.mats[h.mat];
-                const vec3<float> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<float>();
-                vec3<float> emission = mat_emit<float, (kFull >= 3)>(m, h, texc);
-                Ray<float> wo; wo.time = 0.f;                                               // `ray wo;` raytracing.cpp:41
-                vec3<float> att;
+                Hit<R> h;
+                fill_record<R, kFull>(fprims[tv.hit], sc.side(), ray, closest_of(tv, best), sc.need_uv != 0, h);
+                const Mat<R>& m = sc.mats[h.mat];
+                const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
+                vec3<R> emission = mat_emit<R, (kFull >= 3)>(m, h, texc);
+                Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
+                vec3<R> att;
                 bool spec = false;
-                if (mat_shading<float, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec)) {
-                    float pdf, mpdf;
+                if (mat_shading<R, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec)) {
+                    R pdf, mpdf;
                     if (spec) {                                                             // raytracing.cpp:51-54
-                        mpdf = mat_pdf<float, (kFull >= 3)>(g, m, h, wo);
+                        mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
                         pdf = mpdf;
                     }
                     else {                                                                  // raytracing.cpp:55-61
-                        if (uniform<float>(g) < 0.5f) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
-                        mpdf = mat_pdf<float, (kFull >= 3)>(g, m, h, wo);
-                        pdf = 0.5f * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                        if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                        mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
+                        pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
                     }
-                    float inv = 1.0f / pdf;                                                 // raytracing.cpp:69, vec3.hpp:121-123
-                    vec3<float> w = mpdf * att;
+                    R inv = R(1) / pdf;                                                     // raytracing.cpp:69, vec3.hpp:121-123
+                    vec3<R> w = mpdf * att;
                     beta = beta * (inv * w);
                     // a non-finite 1/pdf or weight (also 0 * inf) poisons the sample whatever follows: the recursion multiplies it in
                     if (!rt_finite(beta.x) || !rt_finite(beta.y) || !rt_finite(beta.z)) poisoned = true;
@@ -286,15 +313,15 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
                 alive = false;
                 bool bad = poisoned || !rt_finite(L.x) || !rt_finite(L.y) || !rt_finite(L.z);  // raytracing.cpp:108-110
                 rejected_now = bad;
-                if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<float>(float(path_rays), bad ? 1.f : 0.f, 0.f); bad = false; }
+                if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<R>(R(path_rays), bad ? R(1) : R(0), R(0)); bad = false; }
                 if (!bad) {
-                    float* dst = tile_sum + local * 3;
+                    R* dst = tile_sum + local * 3;
                     __hip_atomic_fetch_add(dst, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(dst + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            else trav_begin(tv, ray, stack_base);
+            else trav_begin(tv, best, ray, stack_base);
         }
         wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
         lap(3);
@@ -304,8 +331,8 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
     int j, i;
     pixel_of((int) threadIdx.x, j, i);
     if (j < a.width && i < a.y_end) {
-        float* out = accum + ((size_t) i * a.width + j) * 3;
-        const float sx = tile_sum[threadIdx.x * 3], sy = tile_sum[threadIdx.x * 3 + 1], sz = tile_sum[threadIdx.x * 3 + 2];
+        R* out = accum + ((size_t) i * a.width + j) * 3;
+        const R sx = tile_sum[threadIdx.x * 3], sy = tile_sum[threadIdx.x * 3 + 1], sz = tile_sum[threadIdx.x * 3 + 2];
         if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sx; out[1] += sy; out[2] += sz; }
         else { out[0] = sx; out[1] = sy; out[2] = sz; }
     }
@@ -316,18 +343,86 @@ __global__ void __launch_bounds__(256, (kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP3
         if (wave_rejected) atomicAdd(&counters[1], wave_rejected);
     }
     if (kCount) {
-        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce;
+        unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce, nz = vs.n_zero;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64);
+            nb += __shfl_down(nb, off, 64); nl += __shfl_down(nl, off, 64); nz += __shfl_down(nz, off, 64);
             wn += __shfl_down(wn, off, 64); wl += __shfl_down(wl, off, 64); wb += __shfl_down(wb, off, 64);
         }
         if (lane == 0) {
-            atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb);
+            atomicAdd(&counters[2], nb); atomicAdd(&counters[3], nl); atomicAdd(&counters[4], wn); atomicAdd(&counters[5], wl); atomicAdd(&counters[6], wb); atomicAdd(&counters[7], nz);
             for (int k = 0; k < 4; k++) atomicAdd(&counters[8 + k], cyc[k]);
             for (int k = 0; k < 3; k++) atomicAdd(&counters[12 + k], census[k]);
         }
     }
+}
+
+// Closest hit of explicit rays through the fast tree, with the render kernel's own culling code (trav_begin, slab_fma / slab_quant,
+// LDS stack) and primitive tests: test hook behind rt_first_hit_tree.  R = double must return the reference walk's primitive, t bits
+// and frontward flag (the closest hit does not depend on the tree), which is what pins RT_MODE_FAST_FP64's traversal.
+template <typename R, bool kQuant>
+__global__ void __launch_bounds__(256) first_hit_tree_kernel(Scene<R> sc, const double* __restrict__ rays, int n, int32_t* __restrict__ prim,
+                                                             R* __restrict__ t_out, int32_t* __restrict__ front)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t stack_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) smem + threadIdx.x * 4u;
+    auto stack_at = [&](uint32_t lds_address) -> lds_u32& { return *(lds_u32*) (uintptr_t) lds_address; };
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;                                  // no barrier below
+    stack_at(stack_base) = (uint32_t) RT_BVH_SENTINEL;
+    const double* p = rays + (size_t) idx * 7;
+    Ray<R> r;
+    r.o = vec3<R>(R(p[0]), R(p[1]), R(p[2]));
+    r.d = vec3<R>(R(p[3]), R(p[4]), R(p[5]));
+    r.time = R(p[6]);
+    const float t_min = consts<float>::tmin;
+    Trav tv; Closest<R> best;
+    trav_begin(tv, best, r, stack_base);
+    while (tv.cur != RT_BVH_SENTINEL) {
+        if (tv.cur >= 0) {
+            float tl, tr; bool hl, hr;
+            int32_t c_left, c_right;
+            if (kQuant) {
+                const QNode nd = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
+                slab_quant<R>(nd, tv, t_min, tl, hl, tr, hr);
+                c_left = nd.left; c_right = nd.right;
+            }
+            else {
+                const BNode nd = *at32(sc.bnodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
+                slab_fma<R>(nd.lb, tv, t_min, tl, hl);
+                slab_fma<R>(nd.rb, tv, t_min, tr, hr);
+                c_left = nd.left; c_right = nd.right;
+            }
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                const int32_t far = left_first ? c_right : c_left;
+                tv.cur = left_first ? c_left : c_right;
+                tv.sp += 1024u;
+                stack_at(tv.sp) = (uint32_t) far;
+            }
+            else if (hl) tv.cur = c_left;
+            else if (hr) tv.cur = c_right;
+            else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+        }
+        else {
+            const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
+            for (int k = 0; k < count; k++) {
+                R t;
+                if (prim_t<R, 2>(sc.fprims[first + k], sc.side(), r, consts<R>::tmin, closest_of(tv, best), t, nullptr)) { set_closest(tv, best, t); tv.hit = first + k; }
+            }
+            tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
+        }
+    }
+    int f = -1;
+    if (tv.hit >= 0) {
+        Hit<R> h;
+        fill_record<R, 2>(sc.fprims[tv.hit], sc.side(), r, closest_of(tv, best), false, h);
+        f = h.front ? 1 : 0;
+    }
+    prim[idx] = tv.hit >= 0 ? sc.fprims[tv.hit].id : -1;
+    t_out[idx] = tv.hit >= 0 ? closest_of(tv, best) : R(0);
+    front[idx] = f;
 }
 
 }  // namespace rt

@@ -42,6 +42,7 @@ template <typename R> struct DeviceScene {
     rt::Scene<R> view{};
     std::vector<void*> owned;
     uint32_t ops_bytes = 0, prims_bytes = 0;   // padded to 16
+    std::vector<uint32_t> leaf_order;          // fp32 scene, during rt_scene_create only: primitive ids in the fast tree's leaf order
 };
 
 template <typename T> int upload(std::vector<void*>& owned, const std::vector<T>& host, const T** dev, size_t pad_to = 16)
@@ -308,12 +309,23 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
     }
 }
 
-template <typename R> int build_fast_tree(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out)
+template <typename R> int build_fast_tree(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out, const DeviceScene<float>* tree);
+// fp64 (RT_MODE_FAST_FP64): the fp32 scene's tree -- nodes only cull, in fp32, for both precisions -- with the fp64 primitive
+// records in its leaf order.  Node arrays stay owned by the fp32 scene.
+template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<double>>& prims, DeviceScene<double>& out, const DeviceScene<float>* tree)
 {
     out.view.bnodes = nullptr; out.view.qnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
+    if (!tree || !tree->view.bnodes) return RT_OK;
+    if (tree->leaf_order.size() * sizeof(rt::Prim<double>) >= (1ull << 32))
+        return fail(RT_EUNSUPPORTED, "fast-mode fp64 record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");
+    std::vector<rt::Prim<double>> ordered(tree->leaf_order.size());
+    for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree->leaf_order[i]];
+    int rc;
+    if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
+    out.view.bnodes = tree->view.bnodes; out.view.qnodes = tree->view.qnodes; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
     return RT_OK;
 }
-template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out)
+template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out, const DeviceScene<float>*)
 {
     std::vector<rtb::Item> items(d->n_prims);
     for (int i = 0; i < d->n_prims; i++) {
@@ -373,6 +385,7 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     }
     std::vector<rt::Prim<float>> ordered(tree.order.size());
     for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree.order[i]];
+    out.leaf_order.assign(tree.order.begin(), tree.order.end());
     int rc;
     if ((rc = upload(out.owned, nodes, &out.view.bnodes))) return rc;
     if ((rc = upload(out.owned, qn, &out.view.qnodes))) return rc;
@@ -382,7 +395,7 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     return RT_OK;
 }
 
-template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, DeviceScene<R>& out)
+template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, DeviceScene<R>& out, const DeviceScene<float>* tree = nullptr)
 {
     const int n_ops = (int) f.op_prim.size();
     std::vector<rt::Op<R>> ops(n_ops);
@@ -448,7 +461,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };
     v.cam.pos = v3(0); v.cam.left_bottom = v3(3); v.cam.horizontal = v3(6); v.cam.vertical = v3(9); v.cam.u = v3(12); v.cam.v = v3(15);
     v.cam.lens_radius = (R) c[21]; v.cam.s0 = (R) c[22]; v.cam.s1 = (R) c[23];
-    if ((rc = build_fast_tree(d, f, prims, out))) return rc;
+    if ((rc = build_fast_tree<R>(d, f, prims, out, tree))) return rc;
     out.ops_bytes = (uint32_t) (((size_t) n_ops * sizeof(rt::Op<R>) + 15) / 16 * 16);
     out.prims_bytes = (uint32_t) (((size_t) d->n_prims * sizeof(rt::Prim<R>) + 15) / 16 * 16);
     return RT_OK;
@@ -533,7 +546,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (!s) return fail(RT_ENOMEM, "out of host memory");
     hipError_t e = hipGetDevice(&s->device);
     if (e != hipSuccess) { delete s; return fail(RT_EHIP, std::string("hipGetDevice: ") + hipGetErrorString(e) + " (no HIP device: the HIP path is the only path)"); }
-    if ((rc = build_device<double>(desc, f, s->d64)) || (rc = build_device<float>(desc, f, s->d32))) { rt_scene_destroy(s); return rc; }
+    if ((rc = build_device<float>(desc, f, s->d32)) || (rc = build_device<double>(desc, f, s->d64, &s->d32))) { rt_scene_destroy(s); return rc; }
+    std::vector<uint32_t>().swap(s->d32.leaf_order);
     s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
     for (int i = 0; i < desc->n_prims; i++) { s->has_volume |= desc->prim_kind[i] == RT_PRIM_VOLUME; s->has_box |= desc->prim_kind[i] == RT_PRIM_BOX; s->only_triangles &= desc->prim_kind[i] == RT_PRIM_TRIANGLE; }
     for (int i = 0; i < desc->n_mats; i++) s->only_triangles &= desc->mat_kind[i] == RT_MAT_PHONG;
@@ -581,7 +595,9 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     if ((long long) p->spp_end - p->spp_begin >= (1 << 23)) return fail(RT_EINVAL, "more than 2^23 - 1 samples per pixel in one call (a tile's items are counted in 32 bits): split the range");
     if ((p->flags & RT_FLAG_WAVEFRONT) && p->max_depth > 65535) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT keeps the depth in 16 bits: max_depth <= 65535");
     if ((long long) p->width * p->height >= (1LL << 31) / 3) return fail(RT_EINVAL, "image too large");
-    if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32 && p->mode != RT_MODE_FP32_REFERENCE_TREE) return fail(RT_EINVAL, "unknown mode");
+    if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32 && p->mode != RT_MODE_FP32_REFERENCE_TREE && p->mode != RT_MODE_FAST_FP64) return fail(RT_EINVAL, "unknown mode");
+    if (p->mode == RT_MODE_FAST_FP64 && (p->flags & (RT_FLAG_LEGACY_LOOP | RT_FLAG_WAVEFRONT)))
+        return fail(RT_EINVAL, "RT_MODE_FAST_FP64 runs the wave kernel only: RT_FLAG_LEGACY_LOOP and RT_FLAG_WAVEFRONT are fp32 A/B variants");
     if (s->n_lights <= 0)
         return fail(RT_EINVAL, "scene.lights is empty: the reference indexes a null light list on the first diffuse hit (group.hpp:115-119)");
     hipStream_t st = static_cast<hipStream_t>(p->stream);
@@ -604,12 +620,17 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
             stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3];
             stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
             for (int k = 0; k < 4; k++) stats->phase_ticks[k] = 0;
+            stats->zero_direction_rays = 0;
         }
         return RT_OK;
     }
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
-    if (p->mode == RT_MODE_REFERENCE_FP64) {
+    if (p->mode == RT_MODE_FAST_FP64) {
+        a.bvh_stack_levels = (uint32_t) s->d64.view.bvh_depth + 2;
+        HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
+    }
+    else if (p->mode == RT_MODE_REFERENCE_FP64) {
         if ((size_t) s->d64.ops_bytes + s->d64.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d64.ops_bytes; a.lds_prims_bytes = s->d64.prims_bytes; }
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
     }
@@ -628,6 +649,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         for (int k = 0; k < 4; k++) stats->phase_ticks[k] = c[8 + k];
         if (getenv("RT_DEBUG") && c[4]) fprintf(stderr, "[rtcore] node-step census per wave step: inner %.2f leaf %.2f hit-known %.2f no-path %.2f\n", (double) c[2] / 2 / c[4], (double) c[12] / c[4], (double) c[13] / c[4], (double) c[14] / c[4]);
         stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
+        stats->zero_direction_rays = c[7];
     }
     return RT_OK;
 }
@@ -730,6 +752,38 @@ int rt_first_hit_fast(rt_scene* s, const double* rays, size_t n, int32_t* prim, 
     if (rc == RT_OK && prim) chk(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost), "download");
     if (rc == RT_OK && t) chk(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost), "download");
     (void) hipFree(d_rays); (void) hipFree(d_prim); (void) hipFree(d_t);
+    return rc;
+}
+
+int rt_first_hit_tree(rt_scene* s, const double* rays, size_t n, int fp64, int32_t* prim, double* t, int32_t* front)
+{
+    if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
+    if (n == 0) return RT_OK;
+    if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    double* d_rays = nullptr; int32_t* d_prim = nullptr; int32_t* d_front = nullptr; void* d_t = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipMalloc((void**) &d_rays, n * 7 * sizeof(double)), "hipMalloc");
+    chk(hipMalloc((void**) &d_prim, n * 4), "hipMalloc");
+    chk(hipMalloc((void**) &d_front, n * 4), "hipMalloc");
+    chk(hipMalloc(&d_t, n * 8), "hipMalloc");
+    if (rc == RT_OK) chk(hipMemcpy(d_rays, rays, n * 7 * sizeof(double), hipMemcpyHostToDevice), "upload rays");
+    if (rc == RT_OK) {
+        if (fp64) chk(rt::launch_first_hit_tree(s->d64.view, d_rays, (int) n, (int) s->quantised, d_prim, static_cast<double*>(d_t), d_front, nullptr), "first_hit_tree launch");
+        else chk(rt::launch_first_hit_tree(s->d32.view, d_rays, (int) n, (int) s->quantised, d_prim, static_cast<float*>(d_t), d_front, nullptr), "first_hit_tree launch");
+    }
+    if (rc == RT_OK) chk(hipDeviceSynchronize(), "first_hit_tree kernel");
+    if (rc == RT_OK && prim) chk(hipMemcpy(prim, d_prim, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && front) chk(hipMemcpy(front, d_front, n * 4, hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK && t) {
+        if (fp64) chk(hipMemcpy(t, d_t, n * 8, hipMemcpyDeviceToHost), "download");
+        else {
+            std::vector<float> tf(n);
+            chk(hipMemcpy(tf.data(), d_t, n * 4, hipMemcpyDeviceToHost), "download");
+            for (size_t i = 0; i < n; i++) t[i] = tf[i];
+        }
+    }
+    (void) hipFree(d_rays); (void) hipFree(d_prim); (void) hipFree(d_front); (void) hipFree(d_t);
     return rc;
 }
 

@@ -10,12 +10,12 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(HERE, "librtcore.so")   # RTCORE_LIB: A/B builds of the same library (tools/)
 
-MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE = 0, 1, 2
+MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE, MODE_FAST_FP64 = 0, 1, 2, 3
 FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_LEGACY_LOOP, FLAG_WAVEFRONT = 1, 2, 4, 8, 16, 32
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 NOALLOC_MAX_RAYS = 32768
 
-EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_buffer_alloc", "rt_buffer_free",
+EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
            "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
            "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
@@ -48,7 +48,7 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rejected_samples", C.c_uint64), ("kernel_ms", C.c_double), ("box_tests", C.c_uint64), ("leaf_tests", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64), ("phase_ticks", C.c_uint64 * 4)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64), ("phase_ticks", C.c_uint64 * 4), ("zero_direction_rays", C.c_uint64)]
 
 
 _lib = None
@@ -70,6 +70,7 @@ def load_library():
         L.rt_first_hit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.rt_first_hit_noalloc.argtypes = L.rt_first_hit.argtypes
+        L.rt_first_hit_tree.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         L.rt_first_hit_fast.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.rt_buffer_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.rt_buffer_free.argtypes = [C.c_void_p]
@@ -182,6 +183,15 @@ class Scene:
         _check(load_library().rt_first_hit_fast(self.h, _ptr(rays, C.c_double), n, _ptr(prim, C.c_int32), _ptr(t, C.c_float)))
         return dict(prim=prim, t=t)
 
+    def first_hit_tree(self, rays, fp64=True):
+        """closest hits through the fast tree with the render kernels' culling code (rt_first_hit_tree)"""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        n = len(rays)
+        out = dict(prim=np.zeros(n, np.int32), t=np.zeros(n), front=np.zeros(n, np.int32))
+        _check(load_library().rt_first_hit_tree(self.h, _ptr(rays, C.c_double), n, int(fp64), _ptr(out["prim"], C.c_int32), _ptr(out["t"], C.c_double),
+                                                _ptr(out["front"], C.c_int32)))
+        return out
+
     def render(self, accum_ptr, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0,
                y_begin=0, y_end=None, stream=None, want_stats=True):
         """accum_ptr: device pointer (int) to width*height*3 doubles (reference mode) or floats (fast mode)."""
@@ -191,12 +201,12 @@ class Scene:
         _check(load_library().rt_render(self.h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st) if want_stats else None))
         return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms), box_tests=int(st.box_tests),
                     leaf_tests=int(st.leaf_tests), wave_node_steps=int(st.wave_node_steps), wave_leaf_steps=int(st.wave_leaf_steps),
-                    wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks]) if want_stats else None
+                    wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks], zero_direction_rays=int(st.zero_direction_rays)) if want_stats else None
 
     def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0, y_begin=0, y_end=None):
         """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats).  With a row
         sub-range the buffer starts zeroed, so rows outside it read as zero."""
-        dt = np.float64 if mode == MODE_REFERENCE_FP64 else np.float32
+        dt = np.float64 if mode in (MODE_REFERENCE_FP64, MODE_FAST_FP64) else np.float32
         n = width * height * 3
         acc = DeviceBuffer(n * np.dtype(dt).itemsize)
         rgb = DeviceBuffer(n)
@@ -204,7 +214,7 @@ class Scene:
             if y_begin != 0 or y_end not in (None, height):
                 acc.upload(np.zeros(n, dt))
             stats = self.render(acc.ptr, width, height, spp_begin, spp_end, max_depth, mode, seed, flags, y_begin, y_end)
-            resolve(acc.ptr, mode == MODE_REFERENCE_FP64, width * height, spp_end - spp_begin, rgb.ptr)
+            resolve(acc.ptr, mode in (MODE_REFERENCE_FP64, MODE_FAST_FP64), width * height, spp_end - spp_begin, rgb.ptr)
             return acc.download(dt, (height, width, 3)), rgb.download(np.uint8, (height, width, 3)), stats
         finally:
             acc.free()

@@ -218,6 +218,11 @@ class Scene:
         n = lib().orc_debug_path(self.h, i, j, k, C.c_uint64(seed), max_depth, _p(out, C.c_double), len(out))
         return out[:n]
 
+    def set_size(self, width, height):
+        """another image size over the same scene and camera fields (keep the aspect ratio)"""
+        lib().orc_set_size(self.h, int(width), int(height))
+        self.width, self.height = int(width), int(height)
+
     def set_early_exit(self, on):
         lib().orc_set_early_exit(self.h, int(on))
 

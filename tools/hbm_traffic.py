@@ -34,13 +34,14 @@ f_kb = sorted(x[0] for x in full)[len(full) // 2]
 w_kb = sorted(x[1] for x in full)[len(full) // 2]
 bytes_per_launch = f_kb * 1024 * 2 + w_kb * 1024
 cfg = bench["config"]
-mode = {"f32": "fp32", "f64": "fp64"}[bench["dtype"]]
-key = f"{'obj' if 'OBJ' in cfg['workload'] else 'random_spheres'}:{cfg['n_primitives']}:{mode}:{cfg['width']}x{cfg['height']}:d{cfg['max_depth']}"
+mode = {"RT_MODE_FAST_FP64": "fp64", "RT_MODE_FAST_FP32": "fp32", "RT_MODE_FP32_REFERENCE_TREE": "fp32ref", "RT_MODE_REFERENCE_FP64": "fp64ref"}[cfg["mode"]]
+workload = "soup" if "soup" in cfg["workload"] else ("obj" if "OBJ" in cfg["workload"] else "random_spheres")
+key = f"{workload}:{cfg['n_primitives']}:{mode}:{cfg['width']}x{cfg['height']}:d{cfg['max_depth']}"
 try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
     table = {}
 table[key] = {"bytes_per_ray": bytes_per_launch / rays, "fetch_KB_per_launch": f_kb, "write_KB_per_launch": w_kb, "rays_per_launch": rays,
-              "spp_profiled": cfg["spp"], "note": "FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by these memory-side counters"}
+              "spp_profiled": cfg["spp"], "round": "r02", "note": "FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by these memory-side counters"}
 json.dump(table, open(out_path, "w"), indent=1)
 print(key, table[key])
