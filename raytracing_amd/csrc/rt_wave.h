@@ -25,8 +25,15 @@
 #ifndef RT_WAVES_OBJ
 #define RT_WAVES_OBJ 5    // waves per SIMD of the OBJ-loader variant (96 VGPRs): measured 4 waves +11 % time, 6 waves +4 %; the other variants lose at 5
 #endif
+// waves per SIMD of the R = double variants.  Unconstrained the OBJ-loader variant takes 208 VGPRs (2 waves) and the node loop -- the
+// same fp32 code as in the float kernel, 70 % of the wave time -- starves for latency hiding: mesh workload at 4K, 8 spp: 40.7 ms at
+// 2 waves, 31.6 at 3, 28.7 at 4 (276 B of scratch per lane, none of it in the node loop: the fp64 triangle test reloads the ray, the
+// shading body spills), 28.0 at 5 (needs a tree <= 23 deep to fit five workgroups' LDS; not taken).  Sphere scenes: 111.6 / 91.4 / 94.2.
+#ifndef RT_WAVES_FP64_OBJ
+#define RT_WAVES_FP64_OBJ 4
+#endif
 #ifndef RT_WAVES_FP64
-#define RT_WAVES_FP64 2   // waves per SIMD of the R = double variants (256 registers)
+#define RT_WAVES_FP64 3
 #endif
 
 namespace rt {
@@ -108,7 +115,7 @@ template <typename R> __device__ inline void slab_quant(const QNode& n, const Tr
 }
 
 template <typename R, bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? RT_WAVES_FP64 : kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut

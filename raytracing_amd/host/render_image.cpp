@@ -1,6 +1,6 @@
 // raytracing_amd/host/render_image.cpp -- the reference's driver (src/cpp/raytracing.cpp:73-137) on the GPU core:
 // same scene-building statements, the pixel/sample loop replaced by scene::render().
-//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell | features | smoke]
+//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell | features | smoke | spheres] [fp64 | fp32 | fp64ref]
 // `render_image output.png 1024 1024 100 10 cornell` is the reference's own main() (raytracing.cpp:77-90,132-137).
 #include <chrono>
 #include <cstdio>
@@ -30,7 +30,7 @@ int main(int argc, char* argv[])
         scn.add_light(new flip(new planexz(123, 423, 147, 412, all ? 553 : 554, new emissive(vec3d(7, 7, 7)))));
         scn.set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(width) / height, 0, 10, 0, 1));
     }
-    else if (argc > 6) {
+    else if (argc > 6 && std::strcmp(argv[6], "spheres")) {
         loader obj_loader(argv[6]);
         scn.add_object(obj_loader.meshes());
         scn.add_light(*obj_loader.lights());
@@ -49,7 +49,8 @@ int main(int argc, char* argv[])
     auto t0 = std::chrono::steady_clock::now();
     rt_render_stats stats;
     std::vector<unsigned char> data;
-    try { data = scn.render(spp, max_depth, true, 0, &stats); }
+    const int mode = argc > 7 && !std::strcmp(argv[7], "fp32") ? RT_MODE_FAST_FP32 : (argc > 7 && !std::strcmp(argv[7], "fp64ref") ? RT_MODE_REFERENCE_FP64 : RT_MODE_FAST_FP64);
+    try { data = scn.render(spp, max_depth, mode, 0, &stats); }
     catch (const std::exception& e) { std::fprintf(stderr, "[ERROR] %s\n", e.what()); return 1; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!rt_write_png(path, width, height, 3, data.data(), true)) { std::fprintf(stderr, "[ERROR] can not write %s\n", path); return 1; }

@@ -58,9 +58,11 @@ public:
 
     // Renders the frame on the current HIP device: the replacement for the pixel/sample loop of render_image
     // (reference raytracing.cpp:96-123).  Returns width*height*3 bytes, row 0 = bottom row, ready for
-    // rt_write_png(..., flip_vertically = true).  fast = fp32 kernels, otherwise fp64 reference-order kernels.
-    std::vector<unsigned char> render(int spp, int max_depth, bool fast = true, unsigned long long seed = 0, rt_render_stats* stats_out = nullptr) const
+    // rt_write_png(..., flip_vertically = true).  mode: RT_MODE_FAST_FP64 (default: the reference's fp64 arithmetic behind the library's
+    // tree), RT_MODE_FAST_FP32, RT_MODE_REFERENCE_FP64 (reference tree and visit order), RT_MODE_FP32_REFERENCE_TREE.
+    std::vector<unsigned char> render(int spp, int max_depth, int mode = RT_MODE_FAST_FP64, unsigned long long seed = 0, rt_render_stats* stats_out = nullptr) const
     {
+        const bool fast = mode == RT_MODE_FAST_FP32 || mode == RT_MODE_FP32_REFERENCE_TREE;      // fp32 sums
         flat_scene flat;
         flatten(flat);
         rt_scene_desc d = flat.desc();
@@ -74,7 +76,7 @@ public:
             check(rt_buffer_alloc(n, &rgb));
             rt_render_params p;
             p.width = width; p.height = height; p.y_begin = 0; p.y_end = height; p.spp_begin = 0; p.spp_end = spp; p.max_depth = max_depth;
-            p.mode = fast ? RT_MODE_FAST_FP32 : RT_MODE_REFERENCE_FP64; p.flags = 0; p.seed = seed; p.stream = nullptr;
+            p.mode = mode; p.flags = 0; p.seed = seed; p.stream = nullptr;
             rt_render_stats stats;
             check(rt_render(dev, &p, accum, &stats));
             if (stats_out) *stats_out = stats;

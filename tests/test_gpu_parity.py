@@ -261,8 +261,9 @@ def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name
     same tree and arithmetic through the lane-synchronous loop and through the multi-kernel wavefront pipeline; reftree =
     reference tree and visit order) vs the fp64 oracle on the same streams.  Tolerance: relative RMSE of the linear radiance <= 5 %
     at 16 spp (the Monte-Carlo noise of these small renders is ~30-60 %, so this is far inside the noise floor and only
-    leaves room for paths whose branches flip under fp32 rounding), <= 2 % of 8-bit values off by more than 8 levels,
-    ray counts within 1 %.  `mixed` is compared with early exit only: its phong-on-sphere paths continue, in the
+    leaves room for paths whose branches flip under fp32 rounding) over all pixels but at most three fireflies (see below),
+    <= 2 % of 8-bit values off by more than 8 levels, ray counts within 1 %.  `mixed` is compared with early exit here
+    (tests/test_gpu_configs.py::test_fp32_mixed_scene_without_early_exit covers it without): its phong-on-sphere paths continue, in the
     reference, as zero-direction rays whose sphere roots are NaN (0/0) -- garbage the fp32 sphere test does not imitate
     (the fp64 mode does, and is compared without early exit above)."""
     tag, make = SCENES[name]
@@ -277,11 +278,15 @@ def test_render_fp32_within_rmse_tolerance(R, golden_dir, name, early, mode_name
     got, rgb, stats = sc.render_to_host(w, h, 0, spp, depth, mode, seed=5, flags=(R.FLAG_EARLY_EXIT if early else 0) | variant)
     # A path whose branch flips under fp32 rounding can be a firefly: the estimator's weight is up to 2 x albedo per bounce
     # (mat_pdf * att / (0.5 * (light_pdf + mat_pdf))), i.e. up to 2^depth x emission for one sample (seen: 1.3e5 in one pixel of
-    # the obj scene in one kernel variant).  The RMSE therefore leaves out the three worst pixels, which must be all there are.
-    err = ((got - want) ** 2).sum(axis=2).ravel()
-    worst = np.argsort(err)[-3:]
-    keep = np.ones(err.size, bool); keep[worst] = False
-    rmse = float(np.sqrt(err[keep].sum() / (3 * keep.sum())) / max(np.sqrt(np.mean(want ** 2)), 1e-12))
+    # the obj scene in one kernel variant).  Nothing is dropped silently: a firefly is a pixel whose error exceeds the frame's rms
+    # radiance; there may be at most three, each must hold a finite, non-negative sum (a legitimate sample of the estimator, not
+    # corrupted arithmetic), and the RMSE bar applies to all other pixels.
+    g = got.astype(np.float64)
+    assert np.isfinite(g).all() and (g >= 0).all()
+    err = np.sqrt(((g - want) ** 2).sum(axis=2))
+    fire = err > np.sqrt(np.mean(want ** 2))
+    assert int(fire.sum()) <= 3, np.argwhere(fire)
+    rmse = float(np.sqrt(np.mean((g[~fire] - want[~fire]) ** 2)) / max(np.sqrt(np.mean(want ** 2)), 1e-12))
     assert rmse < 0.05, rmse
     assert float((np.abs(rgb.astype(int) - want_rgb.astype(int)) > 8).mean()) < 0.02
     assert abs(stats["rays"] - int(cnt[0])) <= 0.01 * int(cnt[0]), (stats["rays"], int(cnt[0]))

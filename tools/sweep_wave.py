@@ -21,6 +21,7 @@ ap.add_argument("--trav", default="0", help="0 = library default")
 ap.add_argument("--node", default="0")
 ap.add_argument("--regen", default="0")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--mode", default="fp32", choices=["fp32", "fp64"], help="RT_MODE_FAST_FP32 or RT_MODE_FAST_FP64")
 ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* bits (16 legacy loop, 32 wavefront pipeline)")
 args = ap.parse_args()
 w, h = args.width, args.height
@@ -33,7 +34,8 @@ elif args.which == "deep":
     hs = HostScene.deep_bounce(w, h, 1)
 else:
     hs = HostScene.random_spheres(w, h, 1)
-acc = R.DeviceBuffer(w * h * 3 * 4)
+acc = R.DeviceBuffer(w * h * 3 * 8)
+MODE = R.MODE_FAST_FP64 if args.mode == 'fp64' else R.MODE_FAST_FP32
 ints = lambda s: [int(x) for x in s.split(",")]
 for tk, nk, rm in itertools.product(ints(args.trav), ints(args.node), ints(args.regen)):
     for name, v in (("RT_TRAV_KEEP", tk), ("RT_NODE_KEEP", nk), ("RT_REGEN_MIN", rm)):
@@ -41,12 +43,12 @@ for tk, nk, rm in itertools.product(ints(args.trav), ints(args.node), ints(args.
         if v:
             os.environ[name] = str(v)
     sc = hs.upload()
-    sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags)
-    runs = [sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=args.flags) for _ in range(2)]
+    sc.render(acc.ptr, w, h, 0, args.spp, args.depth, MODE, seed=1, flags=args.flags)
+    runs = [sc.render(acc.ptr, w, h, 0, args.spp, args.depth, MODE, seed=1, flags=args.flags) for _ in range(2)]
     t = min(r["kernel_ms"] for r in runs)
-    msg = f"{args.which} trav_keep {tk} node_keep {nk} regen_min {rm}: {t:.2f} ms"
+    msg = f"{args.which} {args.mode} trav_keep {tk} node_keep {nk} regen_min {rm}: {t:.2f} ms"
     if args.count:
-        st = sc.render(acc.ptr, w, h, 0, args.spp, args.depth, R.MODE_FAST_FP32, seed=1, flags=R.FLAG_COUNT_TESTS | args.flags)
+        st = sc.render(acc.ptr, w, h, 0, args.spp, args.depth, MODE, seed=1, flags=R.FLAG_COUNT_TESTS | args.flags)
         r = st["rays"]
         msg += (f"  {r / t / 1e3:.0f} Mrays/s | lane-eff shade {r / (64 * st['wave_bounces']):.2f} node {st['box_tests'] / 2 / (64 * max(st['wave_node_steps'], 1)):.2f} "
                 f"leaf {st['leaf_tests'] / (64 * max(st['wave_leaf_steps'], 1)):.2f}")
