@@ -116,12 +116,75 @@ def write_obj_scene(path_obj, path_mtl):
         o.write("\n".join(lines) + "\n")
 
 
+def write_ngon_scene(path_obj, path_mtl):
+    """Polygons with more than four corners, which tinyobjloader ear-clips (tiny_obj_loader.hpp:1715-1936, the built-in method: the
+    reference does not define TINYOBJLOADER_USE_MAPBOX_EARCUT): a concave pentagon and a concave octagon in axis-aligned planes, a
+    concave hexagon (chevron) in a tilted plane, a convex hexagon with normals and uvs, a 7-gon whose first corner is reflex (the
+    clipper has to skip it), over a floor quad and under an emissive pentagon (five corners: lights come out of the clipper too)."""
+    with open(path_mtl, "w") as m:
+        m.write("newmtl floor\nKd 0.70 0.70 0.65\n\nnewmtl red\nKd 0.80 0.25 0.20\n\nnewmtl blue\nKd 0.20 0.30 0.80\nKs 0.5 0.5 0.5\nNs 30.0\n\n")
+        m.write("newmtl green\nKd 0.25 0.70 0.30\n\nnewmtl lamp\nKd 0.0 0.0 0.0\nKe 9.0 9.0 9.0\n")
+    lines = ["mtllib " + os.path.basename(path_mtl)]
+    nv = nvt = nvn = 0
+
+    def poly(name, mtl, pts, normal=None, uvs=None):
+        nonlocal nv, nvt, nvn
+        lines.extend(["o " + name, "usemtl " + mtl])
+        for q in pts:
+            lines.append("v %.6f %.6f %.6f" % tuple(q))
+        if uvs:
+            for q in uvs:
+                lines.append("vt %.6f %.6f" % tuple(q))
+        if normal:
+            lines.append("vn %.6f %.6f %.6f" % tuple(normal))
+            nvn += 1
+        toks = []
+        for k in range(len(pts)):
+            v = nv + k + 1
+            if uvs and normal:
+                toks.append("%d/%d/%d" % (v, nvt + k + 1, nvn))
+            elif normal:
+                toks.append("%d//%d" % (v, nvn))
+            else:
+                toks.append("%d" % v)
+        lines.append("f " + " ".join(toks))
+        nv += len(pts)
+        if uvs:
+            nvt += len(uvs)
+
+    # convex hexagon with a normal and uvs, plane y = 0.6.  First on purpose: the reference loader's scratch vertices are malloc'ed and
+    # uninitialised (loader.hpp:68-110), so a FIRST face without normals takes its fallback normal from garbage (undefined behaviour)
+    hexa = [(math.cos(k * math.pi / 3), math.sin(k * math.pi / 3)) for k in range(6)]
+    poly("hex", "green", [(1.6 + 0.5 * x, 0.6, 0.4 + 0.5 * z) for x, z in hexa], normal=(0, 1, 0), uvs=[(0.5 + 0.5 * x, 0.5 + 0.5 * z) for x, z in hexa])
+    # concave pentagon (a house with its roof pushed in), plane z = -1.2, no normals
+    poly("house", "red", [(-1.6, 0.1, -1.2), (-0.4, 0.1, -1.2), (-0.4, 1.3, -1.2), (-1.0, 0.7, -1.2), (-1.6, 1.3, -1.2)])
+    # concave hexagon (chevron) in a tilted plane: points (u, v) -> origin + u * a + v * b
+    a, b, o = (0.8, 0.1, 0.6), (-0.1, 0.98, 0.15), (0.2, 0.2, -0.9)
+    chev = [(0.0, 0.0), (0.6, 0.35), (1.2, 0.0), (1.2, 0.9), (0.6, 1.25), (0.0, 0.9)]
+    poly("chevron", "blue", [tuple(o[i] + u * a[i] + v * b[i] for i in range(3)) for u, v in chev])
+    # concave octagon (an L), plane x = -2.2, with a normal only
+    ell = [(0.0, -1.0), (0.0, 0.6), (0.5, 0.6), (0.5, -0.4), (1.4, -0.4), (1.4, -1.0), (0.9, -1.0), (0.4, -1.0)]
+    poly("ell", "red", [(-2.2, 0.1 + y, z) for y, z in ell], normal=(1, 0, 0))
+    # 7-gon whose FIRST corner is reflex, plane z = 1.0 facing the camera
+    seven = [(0.0, 0.5), (-0.7, 0.1), (-0.7, 1.2), (0.0, 1.5), (0.7, 1.2), (0.7, 0.1), (0.3, 0.1)]
+    poly("seven", "blue", [(-0.3 + x, y, 1.0) for x, y in seven])
+    # floor quad
+    poly("floor", "floor", [(-3, 0, -3), (-3, 0, 3), (3, 0, 3), (3, 0, -3)], normal=(0, 1, 0))
+    # emissive pentagon facing down
+    pent = [(math.cos(2 * math.pi * k / 5), math.sin(2 * math.pi * k / 5)) for k in range(5)]
+    poly("lamp", "lamp", [(0.9 * x, 3.0, 0.9 * z) for x, z in pent], normal=(0, -1, 0))
+    with open(path_obj, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build the reference harness first: make -C oracle ref")
     os.makedirs(GOLD, exist_ok=True)
     obj = os.path.join(GOLD, "mesh_scene.obj")
     write_obj_scene(obj, os.path.join(GOLD, "mesh_scene.mtl"))
+    ngon = os.path.join(GOLD, "ngon_scene.obj")
+    write_ngon_scene(ngon, os.path.join(GOLD, "ngon_scene.mtl"))
     jobs = {
         "rand": (["rand"], {}),
         "units": (["units"], {}),
@@ -130,6 +193,8 @@ def main():
         "c0_seed7": (["c0", 7, 96, 64, 4, 50], dict(seed=7, width=96, height=64, spp=4, depth=50)),
         "mixed": (["mixed", 3, 64, 48, 16, 20], dict(seed=3, width=64, height=48, spp=16, depth=20)),
         "obj": (["obj", obj, 5, 64, 48, 8, 12], dict(seed=5, width=64, height=48, spp=8, depth=12)),
+        # polygons with more than four corners through tinyobj's ear clipping (arrays keep the harness's "obj_" prefix)
+        "ngon": (["obj", ngon, 6, 64, 48, 8, 12], dict(seed=6, width=64, height=48, spp=8, depth=12)),
         # the reference's own main() scene (raytracing.cpp:77-90: Cornell box, depth 10) at a small size
         "cornell": (["cornell", 1, 56, 56, 16, 10], dict(seed=1, width=56, height=56, spp=16, depth=10)),
         # volume / fog: sphere-bounded media of all_feature_test() (demo.hpp:117-134) over a ground rect

@@ -4,12 +4,14 @@
 //
 // The reference parses with the vendored tinyobjloader 2.0.0, which this repository does not carry; the small parser
 // below reproduces what the loader consumes from it: `v/vt/vn/f/usemtl/mtllib`, negative (relative) indices,
-// float32 storage, quads split along the shorter diagonal (ties -> [0,1,3],[1,2,3]), larger polygons as a fan
-// (tinyobj ear-clips those: documented deviation), material defaults of tinyobj (all colours 0, Ns 1, Ni 1).
+// float32 storage, quads split along the shorter diagonal (ties -> [0,1,3],[1,2,3]), larger polygons ear-clipped by tinyobj's
+// built-in method (ear_clip below; pinned by tests/golden/ngon.npz, a fixture of the real loader), material defaults of tinyobj
+// (all colours 0, Ns 1, Ni 1).
 // Also reproduced: the missing-normal fallback computes the face normal from the scratch vertices as they are at
 // that moment -- corners 1 and 2 still hold the PREVIOUS face while corner 0 is processed (loader.hpp:104-110).
 #pragma once
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,6 +92,65 @@ private:
         }
     }
 
+    // Polygons with more than four corners, the way tinyobjloader 2.0.0's built-in triangulation cuts them (tiny_obj_loader.hpp:1715-1936;
+    // the reference does not build with the mapbox variant): project onto the two axes picked from the first non-degenerate corner,
+    // then clip ears in float32 -- a corner is skipped while it is reflex ("cross * area < 0", with tinyobj's own `area` expression)
+    // or while another remaining corner lies inside its triangle (pnpoly), and the walk gives up after a full round without progress.
+    // Restated here because which triangles come out, and in which order, decides primitive ids, the BVH and every image.
+    static int pnpoly3(const float* vx, const float* vy, float tx, float ty)
+    {
+        int c = 0;
+        for (int i = 0, j = 2; i < 3; j = i++)
+            if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) c = !c;
+        return c;
+    }
+    void ear_clip(const std::vector<corner>& face, std::vector<corner>& tris) const
+    {
+        size_t n = face.size();
+        size_t axes[2] = { 1, 2 };
+        for (size_t k = 0; k < n; k++) {
+            const float* p0 = &pos[(size_t) face[k % n].v * 3];
+            const float* p1 = &pos[(size_t) face[(k + 1) % n].v * 3];
+            const float* p2 = &pos[(size_t) face[(k + 2) % n].v * 3];
+            const float e0x = p1[0] - p0[0], e0y = p1[1] - p0[1], e0z = p1[2] - p0[2];
+            const float e1x = p2[0] - p1[0], e1y = p2[1] - p1[1], e1z = p2[2] - p1[2];
+            const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+            const float eps = 1.1920929e-7f;       // std::numeric_limits<float>::epsilon()
+            if (cx > eps || cy > eps || cz > eps) {
+                if (!(cx > cy && cx > cz)) { axes[0] = 0; if (cz > cx && cz > cy) axes[1] = 1; }
+                break;
+            }
+        }
+        std::vector<corner> rest = face;
+        size_t guess = 0, budget = n, before = n;
+        while (rest.size() > 3 && budget > 0) {
+            n = rest.size();
+            if (guess >= n) guess -= n;
+            if (before != n) { before = n; budget = n; }
+            else budget--;
+            corner ind[3];
+            float vx[3], vy[3];
+            for (size_t k = 0; k < 3; k++) {
+                ind[k] = rest[(guess + k) % n];
+                vx[k] = pos[(size_t) ind[k].v * 3 + axes[0]];
+                vy[k] = pos[(size_t) ind[k].v * 3 + axes[1]];
+            }
+            const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+            const float cross = e0x * e1y - e0y * e1x;
+            const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+            if (cross * area < 0.0f) { guess += 1; continue; }
+            bool overlap = false;
+            for (size_t other = 3; other < n && !overlap; other++) {
+                const corner& o = rest[(guess + other) % n];
+                overlap = pnpoly3(vx, vy, pos[(size_t) o.v * 3 + axes[0]], pos[(size_t) o.v * 3 + axes[1]]) != 0;
+            }
+            if (overlap) { guess += 1; continue; }
+            tris.push_back(ind[0]); tris.push_back(ind[1]); tris.push_back(ind[2]);
+            rest.erase(rest.begin() + (long) ((guess + 1) % n));
+        }
+        if (rest.size() == 3) { tris.push_back(rest[0]); tris.push_back(rest[1]); tris.push_back(rest[2]); }
+    }
+
     static int fix_index(int idx, size_t count) { return idx > 0 ? idx - 1 : (idx < 0 ? (int) count + idx : -1); }
 
     void parse(std::istream& in)
@@ -141,9 +202,8 @@ private:
                     if (s02 < s13) tris = { face[0], face[1], face[2], face[0], face[2], face[3] };
                     else tris = { face[0], face[1], face[3], face[1], face[2], face[3] };
                 }
-                else {
-                    for (size_t k = 1; k + 1 < face.size(); k++) { tris.push_back(face[0]); tris.push_back(face[k]); tris.push_back(face[k + 1]); }
-                }
+                else if (face.size() > 4) ear_clip(face, tris);
+                else tris = face;
                 for (size_t t = 0; t + 2 < tris.size(); t += 3) {
                     for (int c = 0; c < 3; c++) {
                         const corner& idx = tris[t + c];

@@ -285,10 +285,68 @@ def unit_cam(n):
     return out, fields
 
 
+def ear_clip(idx, V):
+    """tinyobjloader 2.0.0's built-in triangulation of a polygon with more than four corners (tiny_obj_loader.hpp:1715-1936), float32:
+    pick two projection axes from the first non-degenerate corner, then clip ears -- skip a corner while `cross * area < 0` (tinyobj's
+    own area expression) or while another remaining corner lies inside its triangle (pnpoly), give up after a round without progress."""
+    F = np.float32
+    P = [[F(c) for c in V[i[0]]] for i in idx]
+    n = len(idx)
+    axes = [1, 2]
+    for k in range(n):
+        p0, p1, p2 = P[k % n], P[(k + 1) % n], P[(k + 2) % n]
+        e0 = [p1[i] - p0[i] for i in range(3)]
+        e1 = [p2[i] - p1[i] for i in range(3)]
+        cx, cy, cz = abs(e0[1] * e1[2] - e0[2] * e1[1]), abs(e0[2] * e1[0] - e0[0] * e1[2]), abs(e0[0] * e1[1] - e0[1] * e1[0])
+        eps = np.finfo(np.float32).eps
+        if cx > eps or cy > eps or cz > eps:
+            if not (cx > cy and cx > cz):
+                axes[0] = 0
+                if cz > cx and cz > cy:
+                    axes[1] = 1
+            break
+
+    def pnpoly(vx, vy, tx, ty):
+        c, j = False, 2
+        for i in range(3):
+            if (vy[i] > ty) != (vy[j] > ty) and tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]:
+                c = not c
+            j = i
+        return c
+
+    rest = list(range(n))
+    tris, guess, budget, before = [], 0, n, n
+    while len(rest) > 3 and budget > 0:
+        n = len(rest)
+        if guess >= n:
+            guess -= n
+        if before != n:
+            before, budget = n, n
+        else:
+            budget -= 1
+        ind = [rest[(guess + k) % n] for k in range(3)]
+        vx = [P[i][axes[0]] for i in ind]
+        vy = [P[i][axes[1]] for i in ind]
+        e0x, e0y, e1x, e1y = vx[1] - vx[0], vy[1] - vy[0], vx[2] - vx[1], vy[2] - vy[1]
+        cross = e0x * e1y - e0y * e1x
+        area = (vx[0] * vy[1] - vy[0] * vx[1]) * F(0.5)
+        if cross * area < 0:
+            guess += 1
+            continue
+        if any(pnpoly(vx, vy, P[rest[(guess + o) % n]][axes[0]], P[rest[(guess + o) % n]][axes[1]]) for o in range(3, n)):
+            guess += 1
+            continue
+        tris.append([idx[i] for i in ind])
+        del rest[(guess + 1) % n]
+    if len(rest) == 3:
+        tris.append([idx[i] for i in rest])
+    return tris
+
+
 # ---------------------------------------------------------------- OBJ -> oracle scene (test-side restatement of loader.hpp:68-171)
 def load_obj_into(scene, path):
     """Parse the small fixture OBJ/MTL the way the reference loader consumes tinyobj's output:
-    float32 attributes promoted to double, fan triangulation, per-face phong material, missing-normal fallback
+    float32 attributes promoted to double, tinyobj's quad split and ear clipping, per-face phong material, missing-normal fallback
     computed from the (possibly stale) scratch vertices (loader.hpp:104-110), emissive faces aliased into lights."""
     f32 = lambda s: float(np.float32(float(s)))
     base = os.path.dirname(path)
@@ -359,8 +417,10 @@ def load_obj_into(scene, path):
                 s02 = np.float32(e02[0] * e02[0] + e02[1] * e02[1]) + e02[2] * e02[2]
                 s13 = np.float32(e13[0] * e13[0] + e13[1] * e13[1]) + e13[2] * e13[2]
                 tris = [[idx[0], idx[1], idx[2]], [idx[0], idx[2], idx[3]]] if s02 < s13 else [[idx[0], idx[1], idx[3]], [idx[1], idx[2], idx[3]]]
+            elif len(idx) > 4:
+                tris = ear_clip(idx, V)
             else:
-                tris = [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+                tris = [idx]
             for tri in tris:
                 for vid, (vi, ti, ni) in enumerate(tri):
                     scratch[vid]["p"] = list(V[vi])

@@ -20,6 +20,7 @@ SCENES = {
     "mixed": ("mixed", lambda gd, m: O.Scene.mixed(m["width"], m["height"], m["seed"])),
     "cornell": ("cornell", lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
     "obj": ("obj", lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
+    "ngon": ("obj", lambda gd, m: O.obj_scene(os.path.join(gd, "ngon_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 # scenes with participating media: the free-flight draw sits inside the intersection test (primitive.hpp:373), so the first-hit
 # entry points (no random stream) do not apply; render tests do
@@ -161,7 +162,7 @@ def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
 
 
 @pytest.mark.parametrize("qnodes", ["0", "1"])
-@pytest.mark.parametrize("name", ["c0_seed1", "c0_seed7", "mixed", "cornell", "obj", "features", "smoke"])
+@pytest.mark.parametrize("name", ["c0_seed1", "c0_seed7", "mixed", "cornell", "obj", "ngon", "features", "smoke"])
 def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, monkeypatch, name, qnodes):
     """RT_MODE_FAST_FP64's traversal (rt_first_hit_tree: the library's SAH tree, fp32 box culling with the render kernel's own code,
     64-byte and 32-byte quantised nodes, fp64 primitive tests in the reference's evaluation order) against the reference walk

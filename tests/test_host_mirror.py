@@ -90,6 +90,9 @@ CASES = {
     "smoke": ("smoke", lambda gd, m: HostScene.smoke(m["width"], m["height"], m["seed"]), lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "obj": ("obj", lambda gd, m: HostScene.obj(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"]),
             lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
+    # polygons with 5..8 corners, concave ones included: tinyobj's ear clipping, restated in host/loader.hpp and in the oracle's loader
+    "ngon": ("obj", lambda gd, m: HostScene.obj(os.path.join(gd, "ngon_scene.obj"), m["width"], m["height"], m["seed"]),
+             lambda gd, m: O.obj_scene(os.path.join(gd, "ngon_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 
 

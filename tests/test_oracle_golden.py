@@ -36,6 +36,7 @@ SCENES = {
     "smoke": ("smoke", 32, lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "features": ("features", 32, lambda gd, m: O.Scene.features(m["width"], m["height"], m["seed"])),
     "obj": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
+    "ngon": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "ngon_scene.obj"), m["width"], m["height"], m["seed"])),
 }
 
 
