@@ -159,10 +159,26 @@ int rt_scene_destroy(rt_scene* scene);
  * trace(emit(x, y)) with rejected samples zeroed -- the body of the k-loop at raytracing.cpp:101-113.
  * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
  * double for RT_MODE_REFERENCE_FP64 and RT_MODE_FAST_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
- * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats.  With RT_FLAG_WAVEFRONT the call
+ * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats (= rt_render_wait).  The scene's device must be
+ * the current one.  With RT_FLAG_WAVEFRONT the call
  * runs a loop of extend / shade kernels over a path pool (84 B per slot, RT_WF_SLOTS slots, default 2 Mi; allocated on the
  * scene's first such call, freed by rt_scene_destroy), polls a device flag and returns when the samples are done. */
 int rt_render(rt_scene* scene, const rt_render_params* params, void* accum_dev, rt_render_stats* stats);
+
+/* Waits for the scene's outstanding rt_render (one launched with stats == NULL) and fills *stats (may be NULL: wait only).  Lets one
+ * host thread start renders on several devices and collect them afterwards. */
+int rt_render_wait(rt_scene* scene, rt_render_stats* stats);
+
+/* One process, several GPUs (no counterpart in the reference, which knows one device): the spp split of SURVEY 8e at the C boundary.
+ * Per device: rt_device_set(d), rt_scene_create (the scene is replicated), a buffer, rt_render of that device's share of the global sample
+ * indices with stats == NULL; then rt_render_wait on each and ONE rt_frame_reduce: dst_dev (on dst_device) += every src_dev[i] (on
+ * src_device[i]), n_values = width*height*3 sums.  The sources reach the destination by peer copies -- one DMA per source over that
+ * source's own xGMI link (the links are point to point), double-buffered against the additions; the call waits for all work on the
+ * devices involved before it starts and returns when the sum is complete.  Sources on the destination's own device are allowed.
+ * (Across processes -- one rank per GPU -- bench.py sums the same buffers with an RCCL reduce instead: raytracing_amd/parallel.py.) */
+int rt_device_count(int* count_out);
+int rt_device_set(int device);
+int rt_frame_reduce(void* dst_dev, int dst_device, void* const* src_dev, const int* src_device, int n_src, int accum_is_fp64, size_t n_values);
 
 /* mean, gamma 0.45, clamp, truncate to 8 bit: raytracing.cpp:115-121.  rgb_dev: n_pixels*3 bytes. */
 int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream);

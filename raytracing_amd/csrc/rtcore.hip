@@ -108,6 +108,7 @@ struct rt_scene {
     bool only_triangles = true;               // every primitive is an RT_PRIM_TRIANGLE and every material an RT_MAT_PHONG (an OBJ-loader scene)
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool pending = false;                     // an rt_render without stats has been launched and not yet waited for
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
     std::vector<void*> wf_owned;
     uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
@@ -484,6 +485,12 @@ __global__ void resolve_kernel(const void* accum, int is_fp64, size_t n_values, 
     rgb[i] = (uint8_t) (int) (c * 255);               // truncation    raytracing.cpp:119-121
 }
 
+template <typename T> __global__ void add_kernel(T* __restrict__ dst, const T* __restrict__ src, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out)
 {
     if (blockIdx.x || threadIdx.x) return;
@@ -600,6 +607,9 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         return fail(RT_EINVAL, "RT_MODE_FAST_FP64 runs the wave kernel only: RT_FLAG_LEGACY_LOOP and RT_FLAG_WAVEFRONT are fp32 A/B variants");
     if (s->n_lights <= 0)
         return fail(RT_EINVAL, "scene.lights is empty: the reference indexes a null light list on the first diffuse hit (group.hpp:115-119)");
+    int current = -1;
+    HIP_TRY(hipGetDevice(&current));
+    if (current != s->device) return fail(RT_EINVAL, "the scene lives on device " + std::to_string(s->device) + " but device " + std::to_string(current) + " is current: call rt_device_set first");
     hipStream_t st = static_cast<hipStream_t>(p->stream);
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
@@ -625,7 +635,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         return RT_OK;
     }
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
-    if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->mode == RT_MODE_FAST_FP64) {
         a.bvh_stack_levels = (uint32_t) s->d64.view.bvh_depth + 2;
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
@@ -639,19 +649,98 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         else if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
         HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st));
     }
-    if (stats) {
-        HIP_TRY(hipEventRecord(s->ev1, st));
-        HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->pending = true;
+    if (stats) return rt_render_wait(s, stats);
+    return RT_OK;
+}
+
+int rt_render_wait(rt_scene* s, rt_render_stats* stats)
+{
+    if (!s) return fail(RT_EINVAL, "scene is required");
+    if (!s->pending) return fail(RT_EINVAL, "rt_render_wait: no render of this scene is outstanding");
+    // events and counters belong to the scene's device; the wait itself needs no particular current device, the read-back does
+    int current = -1;
+    HIP_TRY(hipGetDevice(&current));
+    if (current != s->device) HIP_TRY(hipSetDevice(s->device));
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipEventSynchronize(s->ev1), "hipEventSynchronize");
+    s->pending = false;
+    if (rc == RT_OK && stats) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-        unsigned long long c[16];
-        HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
+        chk(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");
+        unsigned long long c[16] = { 0 };
+        chk(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost), "counter read-back");
         for (int k = 0; k < 4; k++) stats->phase_ticks[k] = c[8 + k];
         if (getenv("RT_DEBUG") && c[4]) fprintf(stderr, "[rtcore] node-step census per wave step: inner %.2f leaf %.2f hit-known %.2f no-path %.2f\n", (double) c[2] / 2 / c[4], (double) c[12] / c[4], (double) c[13] / c[4], (double) c[14] / c[4]);
         stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
         stats->zero_direction_rays = c[7];
     }
+    if (current != s->device) (void) hipSetDevice(current);
+    return rc;
+}
+
+int rt_device_count(int* count_out)
+{
+    if (!count_out) return fail(RT_EINVAL, "count_out is NULL");
+    HIP_TRY(hipGetDeviceCount(count_out));
     return RT_OK;
+}
+
+int rt_device_set(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+int rt_frame_reduce(void* dst_dev, int dst_device, void* const* src_dev, const int* src_device, int n_src, int accum_is_fp64, size_t n_values)
+{
+    if (!dst_dev || n_src < 0 || (n_src && (!src_dev || !src_device))) return fail(RT_EINVAL, "dst_dev and n_src source buffers with their devices are required");
+    if (n_src == 0 || n_values == 0) return RT_OK;
+    const size_t bytes = n_values * (accum_is_fp64 ? 8 : 4);
+    int current = -1;
+    HIP_TRY(hipGetDevice(&current));
+    if (current != dst_device) HIP_TRY(hipSetDevice(dst_device));
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    // two staging buffers on the destination: the peer copy of source i + 1 (a DMA over that source's own xGMI link) runs while source i is added
+    void* stage[2] = { nullptr, nullptr };
+    hipStream_t copy_stream = nullptr, add_stream = nullptr;
+    hipEvent_t copied[2] = { nullptr, nullptr }, added[2] = { nullptr, nullptr };
+    chk(hipMalloc(&stage[0], bytes), "hipMalloc");
+    if (n_src > 1) chk(hipMalloc(&stage[1], bytes), "hipMalloc");
+    chk(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    chk(hipStreamCreateWithFlags(&add_stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 2; k++) { chk(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming), "hipEventCreate"); chk(hipEventCreateWithFlags(&added[k], hipEventDisableTiming), "hipEventCreate"); }
+    // whatever wrote the buffers (renders on the null streams of their devices) must be done before they are read or added to
+    for (int i = 0; i < n_src && rc == RT_OK; i++) {
+        if (!src_dev[i]) { rc = fail(RT_EINVAL, "a source buffer is NULL"); break; }
+        chk(hipSetDevice(src_device[i]), "hipSetDevice");
+        chk(hipDeviceSynchronize(), "hipDeviceSynchronize (source)");
+    }
+    chk(hipSetDevice(dst_device), "hipSetDevice");
+    chk(hipDeviceSynchronize(), "hipDeviceSynchronize (destination)");
+    const unsigned blocks = (unsigned) ((n_values + 255) / 256);
+    for (int i = 0; i < n_src && rc == RT_OK; i++) {
+        const int b = i & 1;
+        if (i >= 2) chk(hipStreamWaitEvent(copy_stream, added[b], 0), "hipStreamWaitEvent");          // the buffer's previous content has been consumed
+        chk(hipMemcpyPeerAsync(stage[b], dst_device, src_dev[i], src_device[i], bytes, copy_stream), "hipMemcpyPeerAsync");
+        chk(hipEventRecord(copied[b], copy_stream), "hipEventRecord");
+        chk(hipStreamWaitEvent(add_stream, copied[b], 0), "hipStreamWaitEvent");
+        if (rc != RT_OK) break;
+        if (accum_is_fp64) hipLaunchKernelGGL(add_kernel<double>, dim3(blocks), dim3(256), 0, add_stream, static_cast<double*>(dst_dev), static_cast<const double*>(stage[b]), n_values);
+        else hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, add_stream, static_cast<float*>(dst_dev), static_cast<const float*>(stage[b]), n_values);
+        chk(hipGetLastError(), "add kernel launch");
+        chk(hipEventRecord(added[b], add_stream), "hipEventRecord");
+    }
+    chk(hipStreamSynchronize(add_stream), "hipStreamSynchronize");
+    chk(hipStreamSynchronize(copy_stream), "hipStreamSynchronize");
+    for (int k = 0; k < 2; k++) { if (copied[k]) (void) hipEventDestroy(copied[k]); if (added[k]) (void) hipEventDestroy(added[k]); if (stage[k]) (void) hipFree(stage[k]); }
+    if (copy_stream) (void) hipStreamDestroy(copy_stream);
+    if (add_stream) (void) hipStreamDestroy(add_stream);
+    if (current != dst_device) (void) hipSetDevice(current);
+    return rc;
 }
 
 int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream)

@@ -1,6 +1,6 @@
 // raytracing_amd/host/render_image.cpp -- the reference's driver (src/cpp/raytracing.cpp:73-137) on the GPU core:
 // same scene-building statements, the pixel/sample loop replaced by scene::render().
-//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell | features | smoke | spheres] [fp64 | fp32 | fp64ref]
+//   render_image [out.png] [width height spp max_depth] [scene.obj | cornell | features | smoke | spheres] [fp64 | fp32 | fp64ref] [devices, e.g. 0,1,2,3]
 // `render_image output.png 1024 1024 100 10 cornell` is the reference's own main() (raytracing.cpp:77-90,132-137).
 #include <chrono>
 #include <cstdio>
@@ -50,7 +50,9 @@ int main(int argc, char* argv[])
     rt_render_stats stats;
     std::vector<unsigned char> data;
     const int mode = argc > 7 && !std::strcmp(argv[7], "fp32") ? RT_MODE_FAST_FP32 : (argc > 7 && !std::strcmp(argv[7], "fp64ref") ? RT_MODE_REFERENCE_FP64 : RT_MODE_FAST_FP64);
-    try { data = scn.render(spp, max_depth, mode, 0, &stats); }
+    std::vector<int> devices;                 // argv[8]: comma-separated HIP device indices to split the frame's samples over
+    if (argc > 8) for (const char* c = argv[8]; *c;) { devices.push_back(std::atoi(c)); while (*c && *c != ',') c++; if (*c == ',') c++; }
+    try { data = scn.render(spp, max_depth, mode, 0, &stats, devices); }
     catch (const std::exception& e) { std::fprintf(stderr, "[ERROR] %s\n", e.what()); return 1; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!rt_write_png(path, width, height, 3, data.data(), true)) { std::fprintf(stderr, "[ERROR] can not write %s\n", path); return 1; }

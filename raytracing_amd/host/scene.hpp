@@ -56,38 +56,69 @@ public:
         out = std::move(f.out);
     }
 
-    // Renders the frame on the current HIP device: the replacement for the pixel/sample loop of render_image
-    // (reference raytracing.cpp:96-123).  Returns width*height*3 bytes, row 0 = bottom row, ready for
-    // rt_write_png(..., flip_vertically = true).  mode: RT_MODE_FAST_FP64 (default: the reference's fp64 arithmetic behind the library's
-    // tree), RT_MODE_FAST_FP32, RT_MODE_REFERENCE_FP64 (reference tree and visit order), RT_MODE_FP32_REFERENCE_TREE.
-    std::vector<unsigned char> render(int spp, int max_depth, int mode = RT_MODE_FAST_FP64, unsigned long long seed = 0, rt_render_stats* stats_out = nullptr) const
+    // Renders the frame: the replacement for the pixel/sample loop of render_image (reference raytracing.cpp:96-123).  Returns
+    // width*height*3 bytes, row 0 = bottom row, ready for rt_write_png(..., flip_vertically = true).
+    // mode: RT_MODE_FAST_FP64 (default: the reference's fp64 arithmetic behind the library's tree), RT_MODE_FAST_FP32,
+    // RT_MODE_REFERENCE_FP64 (reference tree and visit order), RT_MODE_FP32_REFERENCE_TREE.
+    // devices: HIP device indices to spread the frame over (empty: the current device).  The scene is replicated, every device renders
+    // its share of the global sample indices (streams are keyed by the global index: the frame does not depend on the split), the
+    // accumulation buffers are summed onto the first device by rt_frame_reduce (peer copies over xGMI), which resolves.
+    std::vector<unsigned char> render(int spp, int max_depth, int mode = RT_MODE_FAST_FP64, unsigned long long seed = 0, rt_render_stats* stats_out = nullptr,
+                                      std::vector<int> devices = {}) const
     {
-        const bool fast = mode == RT_MODE_FAST_FP32 || mode == RT_MODE_FP32_REFERENCE_TREE;      // fp32 sums
+        const bool fp32_sums = mode == RT_MODE_FAST_FP32 || mode == RT_MODE_FP32_REFERENCE_TREE;
         flat_scene flat;
         flatten(flat);
         rt_scene_desc d = flat.desc();
-        rt_scene* dev = nullptr;
-        check(rt_scene_create(&d, &dev));
-        size_t n = (size_t) width * height * 3;
-        void *accum = nullptr, *rgb = nullptr;
+        const bool current_only = devices.empty();
+        if (current_only) devices.push_back(-1);
+        const int n_dev = (int) devices.size();
+        const size_t n = (size_t) width * height * 3;
+        std::vector<rt_scene*> dev(n_dev, nullptr);
+        std::vector<void*> accum(n_dev, nullptr);
+        void* rgb = nullptr;
         std::vector<unsigned char> image(n);
+        auto release = [&]() {
+            for (int i = 0; i < n_dev; i++) {
+                if (!current_only) rt_device_set(devices[i]);
+                rt_buffer_free(accum[i]); rt_scene_destroy(dev[i]);
+            }
+            if (!current_only) rt_device_set(devices[0]);
+            rt_buffer_free(rgb);
+        };
         try {
-            check(rt_buffer_alloc(n * (fast ? sizeof(float) : sizeof(double)), &accum));
-            check(rt_buffer_alloc(n, &rgb));
+            for (int i = 0; i < n_dev; i++) {
+                if (!current_only) check(rt_device_set(devices[i]));
+                check(rt_scene_create(&d, &dev[i]));
+                check(rt_buffer_alloc(n * (fp32_sums ? sizeof(float) : sizeof(double)), &accum[i]));
+            }
             rt_render_params p;
-            p.width = width; p.height = height; p.y_begin = 0; p.y_end = height; p.spp_begin = 0; p.spp_end = spp; p.max_depth = max_depth;
+            p.width = width; p.height = height; p.y_begin = 0; p.y_end = height; p.max_depth = max_depth;
             p.mode = mode; p.flags = 0; p.seed = seed; p.stream = nullptr;
-            rt_render_stats stats;
-            check(rt_render(dev, &p, accum, &stats));
-            if (stats_out) *stats_out = stats;
-            check(rt_resolve(accum, fast ? 0 : 1, (size_t) width * height, spp, static_cast<uint8_t*>(rgb), nullptr));
+            for (int i = 0; i < n_dev; i++) {       // asynchronous launches: the devices render side by side
+                if (!current_only) check(rt_device_set(devices[i]));
+                p.spp_begin = (int) ((long long) spp * i / n_dev); p.spp_end = (int) ((long long) spp * (i + 1) / n_dev);
+                check(rt_render(dev[i], &p, accum[i], nullptr));
+            }
+            rt_render_stats total{};
+            for (int i = 0; i < n_dev; i++) {
+                rt_render_stats st{};
+                check(rt_render_wait(dev[i], &st));
+                total.rays += st.rays; total.rejected_samples += st.rejected_samples;
+                if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;
+            }
+            if (stats_out) *stats_out = total;
+            if (n_dev > 1) check(rt_frame_reduce(accum[0], devices[0], &accum[1], &devices[1], n_dev - 1, fp32_sums ? 0 : 1, n));
+            if (!current_only) check(rt_device_set(devices[0]));
+            check(rt_buffer_alloc(n, &rgb));
+            check(rt_resolve(accum[0], fp32_sums ? 0 : 1, (size_t) width * height, spp, static_cast<uint8_t*>(rgb), nullptr));
             check(rt_buffer_download(image.data(), rgb, n));
         }
         catch (...) {
-            rt_buffer_free(accum); rt_buffer_free(rgb); rt_scene_destroy(dev);
+            release();
             throw;
         }
-        rt_buffer_free(accum); rt_buffer_free(rgb); rt_scene_destroy(dev);
+        release();
         return image;
     }
 

@@ -15,7 +15,7 @@ FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 NOALLOC_MAX_RAYS = 32768
 
-EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
+EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_wait", "rt_device_count", "rt_device_set", "rt_frame_reduce", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
            "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
            "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
@@ -66,6 +66,10 @@ def load_library():
         L.rt_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
+        L.rt_render_wait.argtypes = [C.c_void_p, C.POINTER(RenderStats)]
+        L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.rt_device_set.argtypes = [C.c_int]
+        L.rt_frame_reduce.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_size_t]
         L.rt_resolve.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.rt_first_hit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -203,6 +207,12 @@ class Scene:
                     leaf_tests=int(st.leaf_tests), wave_node_steps=int(st.wave_node_steps), wave_leaf_steps=int(st.wave_leaf_steps),
                     wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks], zero_direction_rays=int(st.zero_direction_rays)) if want_stats else None
 
+    def render_wait(self):
+        """collect a render started with want_stats=False (rt_render_wait)"""
+        st = RenderStats()
+        _check(load_library().rt_render_wait(self.h, C.byref(st)))
+        return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms))
+
     def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0, y_begin=0, y_end=None):
         """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats).  With a row
         sub-range the buffer starts zeroed, so rows outside it read as zero."""
@@ -266,6 +276,20 @@ def checkpoint_load(path, accum_ptr, is_fp64, width, height):
     spp, seed = C.c_int32(), C.c_uint64()
     _check(load_library().rt_checkpoint_load(os.fsencode(path), C.c_void_p(accum_ptr), int(is_fp64), width, height, C.byref(spp), C.byref(seed)))
     return spp.value, seed.value
+
+
+def frame_reduce(dst_ptr, dst_device, src_ptrs, src_devices, is_fp64, n_values):
+    """dst += every source buffer (rt_frame_reduce: peer copies + adds; one process driving several devices)"""
+    n = len(src_ptrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(p) for p in src_ptrs])
+    devs = (C.c_int * max(n, 1))(*src_devices)
+    _check(load_library().rt_frame_reduce(C.c_void_p(dst_ptr), dst_device, ptrs, devs, n, int(is_fp64), n_values))
+
+
+def device_count():
+    n = C.c_int()
+    _check(load_library().rt_device_count(C.byref(n)))
+    return n.value
 
 
 def resolve(accum_ptr, is_fp64, n_pixels, spp, rgb_ptr, stream=None):

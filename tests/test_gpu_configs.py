@@ -190,6 +190,14 @@ def test_render_image_driver_writes_the_resolved_frame(R, tmp_path):
     sc = hs.upload()
     _, rgb, _ = sc.render_to_host(96, 96, 0, 4, 10, R.MODE_FAST_FP64, seed=0)
     assert np.array_equal(png[::-1], rgb)
+    # the same frame with its samples split over "two devices" (device 0 twice: two scene replicas, two buffers, rt_frame_reduce):
+    # the sums differ from the single launch's by the rounding of one addition, so the 8-bit frame may differ by one level on a
+    # handful of values at most
+    out2 = str(tmp_path / "cornell2.png")
+    res = subprocess.run([exe, out2, "96", "96", "4", "10", "cornell", "fp64", "0,0"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    diff = np.abs(read_png_any(out2).astype(int) - png.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
     sc.destroy(); hs.free()
 
 

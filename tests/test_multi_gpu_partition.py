@@ -63,3 +63,101 @@ def test_two_rank_spp_split_matches_single_process(tmp_path):
     assert np.allclose(got["accum"], want, rtol=1e-13, atol=0)      # only the fp64 summation order differs
     assert int(got["rays"][0]) == int(cnt[0])
     assert np.abs(got["rgb"].astype(int) - want_rgb.astype(int)).max() <= 1
+
+
+def _gpu_worker(rank, world, port, spp, split, steps, out_path):
+    """One rank of bench.py's N > 1 step with the HIP path: render this rank's share on the GPU (both ranks share device 0 on a one-GPU
+    box), SUM-reduce onto rank 0 (gloo: through the host), resolve.  `steps` repeats the step as bench.py's timed loop does."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import raytracing_amd as R
+    from raytracing_amd.host_scenes import HostScene
+    from raytracing_amd.parallel import reduce_frame, row_range, sample_range
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    w, h, depth = 64, 48, 12
+    hs = HostScene.random_spheres(w, h, 1)
+    sc = hs.upload()
+    k0, k1 = sample_range(rank, world, spp) if split == "spp" else (0, spp)
+    y0, y1 = (0, h) if split == "spp" else row_range(rank, world, h)
+    accum = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    rays = 0
+    for _ in range(steps):
+        if split == "rows":
+            accum[:y0].zero_(); accum[y1:].zero_()
+        st = sc.render(accum.data_ptr(), w, h, k0, k1, depth, R.MODE_REFERENCE_FP64, seed=4, y_begin=y0, y_end=y1)
+        host = accum.cpu()
+        reduce_frame(host, world, dst=0)
+        accum.copy_(host)
+        rays = st["rays"]
+    total = torch.tensor([float(rays)], dtype=torch.float64)
+    dist.all_reduce(total)
+    if rank == 0:
+        np.savez(out_path, accum=accum.cpu().numpy(), rays=total.numpy())
+    dist.barrier()
+    sc.destroy(); hs.free()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split,steps", [("spp", 1), ("rows", 2)])
+def test_two_ranks_on_the_hip_path_match_one_rank(tmp_path, split, steps):
+    """The N > 1 step of bench.py with the HIP kernels doing the rendering (2 ranks, gloo, one device): spp split -- fp64 sums equal the
+    one-rank frame to the rounding of one addition per pixel; rows split over two steps -- the frame does not grow with the step count
+    (a rank clears the rows it does not own before every step) and equals the one-rank frame bit for bit (disjoint rows: x + 0)."""
+    import torch.multiprocessing as mp
+    import raytracing_amd as R
+    from raytracing_amd.host_scenes import HostScene
+    spp = 6
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "frame.npz")
+    mp.spawn(_gpu_worker, args=(2, port, spp, split, steps, out), nprocs=2, join=True)
+    got = np.load(out)
+    hs = HostScene.random_spheres(64, 48, 1)
+    sc = hs.upload()
+    want, _, st = sc.render_to_host(64, 48, 0, spp, 12, R.MODE_REFERENCE_FP64, seed=4)
+    if split == "rows":
+        assert np.array_equal(got["accum"].view(np.uint64), want.view(np.uint64))
+    else:
+        assert np.allclose(got["accum"], want, rtol=1e-13, atol=0)
+    assert int(got["rays"][0]) == st["rays"]
+    sc.destroy(); hs.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode_name", ["fp64ref", "fast64", "fast32"])
+def test_frame_reduce_sums_partial_frames_of_several_scenes(mode_name):
+    """rt_frame_reduce (one process, several devices; here three scene replicas on the one device there is): three partial frames over
+    disjoint sample ranges, started without stats, collected with rt_render_wait, summed onto the first -- equal to the single render
+    of all samples up to the rounding of two additions per value (fp64: 1e-13; fp32 fast mode: 1e-5, its tile sums add in completion
+    order anyway), ray counts add up exactly."""
+    import raytracing_amd as R
+    from raytracing_amd.host_scenes import HostScene
+    mode, dt, tol = {"fp64ref": (R.MODE_REFERENCE_FP64, np.float64, 1e-13), "fast64": (R.MODE_FAST_FP64, np.float64, 1e-13),
+                     "fast32": (R.MODE_FAST_FP32, np.float32, 1e-5)}[mode_name]
+    assert R.device_count() >= 1
+    w, h, depth, spp = 80, 48, 12, 9
+    hs = HostScene.random_spheres(w, h, 1)
+    scenes = [hs.upload() for _ in range(3)]
+    bufs = [R.DeviceBuffer(w * h * 3 * np.dtype(dt).itemsize) for _ in range(3)]
+    ranges = [(0, 2), (2, 5), (5, 9)]
+    for sc, b, (k0, k1) in zip(scenes, bufs, ranges):
+        assert sc.render(b.ptr, w, h, k0, k1, depth, mode, seed=4, want_stats=False) is None
+    stats = [sc.render_wait() for sc in scenes]
+    with pytest.raises(R.RtError):
+        scenes[0].render_wait()                    # nothing outstanding any more
+    R.frame_reduce(bufs[0].ptr, 0, [bufs[1].ptr, bufs[2].ptr], [0, 0], dt == np.float64, w * h * 3)
+    got = bufs[0].download(dt, (h, w, 3))
+    want, _, st = scenes[0].render_to_host(w, h, 0, spp, depth, mode, seed=4)
+    assert np.allclose(got, want, rtol=tol, atol=tol * float(np.abs(want).max()))
+    assert sum(s["rays"] for s in stats) == st["rays"]
+    R.frame_reduce(bufs[0].ptr, 0, [], [], dt == np.float64, w * h * 3)       # no sources: a no-op
+    assert np.array_equal(bufs[0].download(dt, (h, w, 3)), got)
+    for b in bufs:
+        b.free()
+    for sc in scenes:
+        sc.destroy()
+    hs.free()
