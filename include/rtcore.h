@@ -125,6 +125,10 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_WAVEFRONT 32     /* RT_MODE_FAST_FP32 as a multi-kernel wavefront pipeline over a path pool in HBM (rt_wavefront.h) instead of
                                     one kernel; blocks until the samples are done.  Slower than the default on the measured workloads. */
 
+#define RT_FLAG_QUEUE 64         /* A/B: the fast modes through the decoupled kernel (rt_queue.h: per-wave path pools in global memory, lanes hand
+                                    finished traversals to full-width shade passes and take queued rays at once).  Same samples and sums as the
+                                    default kernel up to the order of the tile additions.  Scenes with boxes, volumes or instances ignore it. */
+
 typedef struct rt_render_params {
     int32_t width, height;       /* image size: pixel (j,i) -> sample position as raytracing.cpp:102-103 */
     int32_t y_begin, y_end;      /* rows rendered by this call (tile split); 0, height for the whole frame */

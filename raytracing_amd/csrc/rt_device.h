@@ -91,6 +91,7 @@ struct alignas(16) QNode {
     uint32_t q[3];
     int32_t left, right;
 };
+#define RT_Q_SLOTS_MAX 256          // rt_queue.h: path slots per wave (list entries are one byte)
 #define RT_BVH_SENTINEL ((int32_t) 0x80000000)
 #define RT_BVH_STACK_MAX 64
 #ifndef RT_WAVES_FP32
@@ -1055,6 +1056,9 @@ struct RenderArgs {
     uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
     uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances, 3 triangles + phong only
     uint32_t xcd_tiles;                        // != 0: rt_wave.h deals 8 x 8-tile super-tiles to the 8 XCDs (grid padded to whole rounds of 8 super-tiles)
+    // rt_queue.h (decoupled traversal / shading): slots per wave (0: the rt_wave.h kernel), pools allocated, lanes that must wait before a
+    // hand-off is run, known hits from which a starved wave shades a partial pass
+    uint32_t q_slots, q_pools, q_handoff_min, q_shade_starved;
 };
 
 // ------------------------------------------------------------------ render kernel

@@ -5,6 +5,7 @@
 #include "rt_launch.h"
 #ifdef RT_WITH_WAVE
 #include "rt_wave.h"
+#include "rt_queue.h"
 #endif
 
 namespace rt {
@@ -27,9 +28,31 @@ hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const S
     else hipLaunchKernelGGL((render_wave_kernel<R, false, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
     return hipGetLastError();
 }
+
+// one variant of the decoupled kernel (rt_queue.h)
+template <typename R, bool kQuant, int kFull>
+hipError_t launch_queue(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, void* pools, unsigned int* locks)
+{
+    if (lds > 48 * 1024) {
+        static thread_local size_t configured = 0;
+        if (lds > configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_queue_kernel<R, false, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_queue_kernel<R, true, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+    }
+    if (count) hipLaunchKernelGGL((render_queue_kernel<R, true, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters, static_cast<QSlot<R>*>(pools), locks);
+    else hipLaunchKernelGGL((render_queue_kernel<R, false, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters, static_cast<QSlot<R>*>(pools), locks);
+    return hipGetLastError();
+}
 #endif
 
-hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_REAL* accum, unsigned long long* counters, hipStream_t s)
+#ifdef RT_WITH_WAVE
+size_t queue_slot_bytes(RT_REAL) { return sizeof(QSlot<RT_REAL>); }
+#endif
+
+hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_REAL* accum, unsigned long long* counters, hipStream_t s, void* q_pools, unsigned int* q_locks)
 {
     RenderArgs a = a_in;
     const int tiles_x = (a.width + 15) / 16, tiles_y = (a.y_end - a.y_begin + 15) / 16;
@@ -49,6 +72,14 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 #ifdef RT_WITH_WAVE
     if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
         if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64)); }
+        if (a.q_slots > 0 && q_pools && q_locks && (a.kinds == 0 || a.kinds == 3)) {          // decoupled kernel (rt_queue.h): two more KiB of LDS for the lists
+            const size_t qlds = lds + 16 + 4 * RT_Q_SLOTS_MAX;
+            if (a.kinds == 3) {
+                if (a.quantised) return launch_queue<RT_REAL, true, 3>(count, grid, qlds, s, sc, a, accum, counters, q_pools, q_locks);
+                return launch_queue<RT_REAL, false, 3>(count, grid, qlds, s, sc, a, accum, counters, q_pools, q_locks);
+            }
+            return launch_queue<RT_REAL, false, 0>(count, grid, qlds, s, sc, a, accum, counters, q_pools, q_locks);
+        }
         // variants by scene content (rt_device.h prim_t): 2 instances (unquantised nodes), 1 boxes or volumes, 3 an OBJ-loader scene, 0 the rest
         if (a.kinds == 2) return launch_wave<RT_REAL, false, 2>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 1) return launch_wave<RT_REAL, false, 1>(count, grid, lds, s, sc, a, accum, counters);

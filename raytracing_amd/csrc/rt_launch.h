@@ -6,8 +6,11 @@
 #include "rt_wavefront.h"
 
 namespace rt {
-hipError_t launch_render(const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, hipStream_t s);
-hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* accum, unsigned long long* counters, hipStream_t s);
+// q_pools / q_locks: path pools and their locks for the decoupled kernel (rt_queue.h), used when a.q_slots > 0; may be null otherwise
+hipError_t launch_render(const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, hipStream_t s, void* q_pools = nullptr, unsigned int* q_locks = nullptr);
+hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* accum, unsigned long long* counters, hipStream_t s, void* q_pools = nullptr, unsigned int* q_locks = nullptr);
+size_t queue_slot_bytes(double);
+size_t queue_slot_bytes(float);
 // RT_MODE_FAST_FP32: wavefront loop over a path pool (rt_wavefront.h).  Blocks until the frame's samples are done; fills
 // out[0..6] = rays, rejected samples, box tests, leaf tests, wave node steps, wave leaf steps, shade waves.
 struct WfBuffers { WfPool pool; uint32_t capacity; int bvh_depth; void* host_pinned; };

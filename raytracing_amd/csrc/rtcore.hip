@@ -109,6 +109,11 @@ struct rt_scene {
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool pending = false;                     // an rt_render without stats has been launched and not yet waited for
+    // rt_queue.h: path pools (per precision) and their locks, allocated on the scene's first decoupled render
+    void* q_pools[2] = { nullptr, nullptr };
+    unsigned int* q_locks[2] = { nullptr, nullptr };
+    uint32_t q_n_pools = 2048;                // > workgroups the chip holds at once (256 CUs x <= 5 of these workgroups)
+    uint32_t queue = 0, q_slots = 192, q_handoff_min = 16, q_shade_starved = 16;   // RT_QUEUE / RT_Q_SLOTS / RT_Q_HANDOFF / RT_Q_STARVED
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
     std::vector<void*> wf_owned;
     uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
@@ -575,6 +580,10 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_QUEUE")) s->queue = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RT_Q_SLOTS")) s->q_slots = (uint32_t) std::min(RT_Q_SLOTS_MAX, std::max(64, std::atoi(env)));
+    if (const char* env = std::getenv("RT_Q_HANDOFF")) s->q_handoff_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_Q_STARVED")) s->q_shade_starved = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
     *scene_out = s;
     return RT_OK;
 }
@@ -585,6 +594,7 @@ int rt_scene_destroy(rt_scene* s)
     release(s->d64); release(s->d32);
     for (void* q : s->wf_owned) (void) hipFree(q);
     if (s->wf.host_pinned) (void) hipHostFree(s->wf.host_pinned);
+    for (int k = 0; k < 2; k++) { if (s->q_pools[k]) (void) hipFree(s->q_pools[k]); if (s->q_locks[k]) (void) hipFree(s->q_locks[k]); }
     if (s->counters) (void) hipFree(s->counters);
     if (s->ev0) (void) hipEventDestroy(s->ev0);
     if (s->ev1) (void) hipEventDestroy(s->ev1);
@@ -636,9 +646,24 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     }
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
+    // the decoupled kernel (rt_queue.h) serves the fast modes of scenes without boxes, volumes (their free-flight draw needs the path's
+    // stream inside the traversal) or instances
+    const bool fast_mode = p->mode == RT_MODE_FAST_FP64 || p->mode == RT_MODE_FAST_FP32;
+    void* q_pools = nullptr; unsigned int* q_locks = nullptr;
+    if (fast_mode && (s->queue || (p->flags & RT_FLAG_QUEUE)) && !(p->flags & RT_FLAG_LEGACY_LOOP) && (a.kinds == 0 || a.kinds == 3) && p->max_depth < (1 << 21)) {
+        const int k = p->mode == RT_MODE_FAST_FP64 ? 1 : 0;
+        if (!s->q_pools[k]) {
+            const size_t bytes = (size_t) s->q_n_pools * 4 * RT_Q_SLOTS_MAX * (k ? rt::queue_slot_bytes(0.0) : rt::queue_slot_bytes(0.0f));
+            HIP_TRY(hipMalloc(&s->q_pools[k], bytes));
+            HIP_TRY(hipMalloc((void**) &s->q_locks[k], s->q_n_pools * sizeof(unsigned int)));
+        }
+        HIP_TRY(hipMemsetAsync(s->q_locks[k], 0, s->q_n_pools * sizeof(unsigned int), st));
+        q_pools = s->q_pools[k]; q_locks = s->q_locks[k];
+        a.q_slots = s->q_slots; a.q_pools = s->q_n_pools; a.q_handoff_min = s->q_handoff_min; a.q_shade_starved = s->q_shade_starved;
+    }
     if (p->mode == RT_MODE_FAST_FP64) {
         a.bvh_stack_levels = (uint32_t) s->d64.view.bvh_depth + 2;
-        HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
+        HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st, q_pools, q_locks));
     }
     else if (p->mode == RT_MODE_REFERENCE_FP64) {
         if ((size_t) s->d64.ops_bytes + s->d64.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d64.ops_bytes; a.lds_prims_bytes = s->d64.prims_bytes; }
@@ -647,7 +672,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     else {
         if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) s->d32.view.bvh_depth + 2;
         else if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
-        HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st));
+        HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st, q_pools, q_locks));
     }
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;

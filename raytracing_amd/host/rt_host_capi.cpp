@@ -130,6 +130,23 @@ rth_scene* rth_build_features(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// all_feature_test() LIT: the demo's own rect light is not flipped and shines upwards, so the scene above renders black; here the light
+// is a flipped rect just under it (as an object and as the light), the way render_image's `features` scene is built
+rth_scene* rth_build_features_lit(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        scn.add_object(all_feature_test());
+        scn.add_object(new flip(new planexz(123, 423, 147, 412, 553, new emissive(vec3d(7, 7, 7)))));
+        scn.add_light(new flip(new planexz(123, 423, 147, 412, 553, new emissive(vec3d(7, 7, 7)))));
+        scn.set_camera(camera(vec3d(478, 278, -600), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, double(width) / height, 0, 10, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
 // volume / fog: smoke_scene() (demo.hpp) under its flipped rect light, camera of the classic final-scene view
 rth_scene* rth_build_smoke(int width, int height, unsigned seed)
 {
