@@ -345,8 +345,11 @@ def main():
                        "parallelism": f"{args.split} split over {world} GPU(s), RCCL reduce of the accumulation buffer" if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims),
                        "zero_direction_ray_share": round(zero_share, 4),
-                       "zero_direction_note": "share of rays_per_step traced with direction (0,0,0): phong leaves wo unset (material.hpp:225-229,252-254), "
-                                              "the reference traces and counts such a ray (it misses everything); they cost a few node visits each"},
+                       "zero_direction_note": "share of rays_per_step that are rays with direction (0,0,0): phong leaves wo unset (material.hpp:225-229,252-254); the "
+                                              "reference traces and counts such a ray, which can only miss in a scene of triangles (polygon.hpp:95-97), so the fast "
+                                              "kernels skip its traversal there (same result, still counted, as SURVEY 8d counts trace() calls); "
+                                              "`value_without_zero_direction_rays` leaves them out of the rate"},
+            "value_without_zero_direction_rays": round(total_rays * (1.0 - zero_share) / elapsed / 1e6, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_fp32 and args.mode == "fp64":

@@ -156,6 +156,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         q_load_ray(pool + slot, ray);
                         trav_begin(tv, best, ray, stack_base);
+                        if (kFull >= 3 && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;   // see rt_wave.h
                     }
                 }
                 n_rays -= k;

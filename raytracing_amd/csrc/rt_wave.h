@@ -328,7 +328,14 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            else trav_begin(tv, best, ray, stack_base);
+            else {
+                trav_begin(tv, best, ray, stack_base);
+                // phong leaves `wo` unset (material.hpp:225-229,252-254): a ray with direction (0,0,0), a fifth of the OBJ workload's rays.  The
+                // reference traces it all the same, and against triangles it can only miss (polygon.hpp:95-97: a = e1 . (0 x e2) = 0), so in
+                // a scene of triangles alone its traversal is skipped: same result, same ray count (it is still a ray), no node visits.
+                // (Spheres answer such a ray with NaN roots: other variants walk on.)
+                if (kFull >= 3 && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;
+            }
         }
         wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
         lap(3);
