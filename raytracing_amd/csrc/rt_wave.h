@@ -278,9 +278,9 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
         const bool shading = alive && tv.cur == RT_BVH_SENTINEL;
         wave_rays += (unsigned long long) __popcll(__ballot(shading));
         if (kCount && shading && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) vs.n_zero++;
-        bool rejected_now = false;
+        bool rejected_now = false, zero_ray = false;
         if (shading) {
-            const int path_rays = a.max_depth - depth + 1;               // this path's segments so far, this one included
+            int path_rays = a.max_depth - depth + 1;                     // this path's segments so far, this one included
             vec3<R> L;
             if (kCount && first_active_lane()) vs.w_bounce++;
             bool done = true;
@@ -313,6 +313,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     depth--;
                     done = depth <= 0;
                     if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
+                    // phong leaves `wo` unset (material.hpp:225-229,252-254): a ray with direction (0,0,0), a fifth of the OBJ workload's rays.  The
+                    // reference traces it all the same, and against triangles it can only miss (polygon.hpp:95-97: a = e1 . (0 x e2) = 0; its
+                    // box walk only enters the boxes around the origin).  In a scene of triangles alone that segment is therefore finished
+                    // here: counted as the ray it is, black, the path ends (rejected: its pdf is 0).  Before, the slab test's nudge of zero
+                    // components made it a diagonal ray that walked the whole tree: mesh workload 152 -> 69 ms per 64 spp.
+                    // (Spheres answer such a ray with NaN roots: the other variants walk on.)
+                    if (kFull >= 3 && !done && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) { zero_ray = true; done = true; path_rays++; }
                 }
                 else L = beta * emission;                                                   // the path ends on an emitter (or absorber)
             }
@@ -328,15 +335,10 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            else {
-                trav_begin(tv, best, ray, stack_base);
-                // phong leaves `wo` unset (material.hpp:225-229,252-254): a ray with direction (0,0,0), a fifth of the OBJ workload's rays.  The
-                // reference traces it all the same, and against triangles it can only miss (polygon.hpp:95-97: a = e1 . (0 x e2) = 0), so in
-                // a scene of triangles alone its traversal is skipped: same result, same ray count (it is still a ray), no node visits.
-                // (Spheres answer such a ray with NaN roots: other variants walk on.)
-                if (kFull >= 3 && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;
-            }
+            else trav_begin(tv, best, ray, stack_base);
         }
+        wave_rays += (unsigned long long) __popcll(__ballot(zero_ray));
+        if (kCount && zero_ray) vs.n_zero++;
         wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
         lap(3);
     }
