@@ -129,6 +129,15 @@ typedef struct rt_scene_desc {
                                     finished traversals to full-width shade passes and take queued rays at once).  Same samples and sums as the
                                     default kernel up to the order of the tile additions.  Scenes with boxes, volumes or instances ignore it. */
 
+#define RT_FLAG_COMPAT_FIXED 128 /* No counterpart in the reference (SURVEY 7 / 9 "compat=fixed"): the reference's estimator with three defects repaired,
+                                    for pictures rather than parity.  (1) A specular lobe is a delta and weighs its attenuation: the reference divides by
+                                    material::pdf, which is 0 for a dielectric and for a metal reflection below the surface, so every glass sample
+                                    is 0 * inf and rejected; a specular direction below the surface is absorbed.  (2) phong sets wo: mirror
+                                    reflection for its specular lobe, a cosine lobe for its diffuse one, whose pdf is not re-rolled.  (3) A
+                                    diffuse direction of zero probability ends the path with nothing instead of 0/0.  Checked against the oracle's
+                                    restatement of the same rules on the same streams (orc_set_compat_fixed).  Wave kernel and reference-order kernels;
+                                    RT_FLAG_QUEUE / RT_FLAG_WAVEFRONT / RT_FLAG_LEGACY_LOOP with it are refused. */
+
 typedef struct rt_render_params {
     int32_t width, height;       /* image size: pixel (j,i) -> sample position as raytracing.cpp:102-103 */
     int32_t y_begin, y_end;      /* rows rendered by this call (tile split); 0, height for the whole frame */

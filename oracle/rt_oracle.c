@@ -228,6 +228,7 @@ struct orc_scene {
     int* root_entry;
     uint64_t rays;
     int early_exit;   /* stop a path once its sample is known to be rejected (same image, fewer rays) */
+    int compat_fixed; /* no counterpart in the reference: the estimator with its defects repaired (see orc_set_compat_fixed) */
 };
 
 static v3 tex_color(const orc_scene* s, int ti, v3 p, v2 uv)
@@ -312,6 +313,7 @@ static int mat_shading(const orc_scene* s, orc_rng* g, const orc_mat* m, const r
         *wo = mkray(x->pos, vadd(next, fuzz), wi->time, wi->t_min, wi->t_max);
         *att = tex_color(s, m->tex, x->pos, x->uv);
         *spec = 1;
+        if (s->compat_fixed && !(vdot(wo->d, x->normal) > 0)) return 0;     /* fixed: a fuzzed reflection below the surface is absorbed */
         return 1;
     }
     case ORC_MAT_DIELECTRIC:                                             /* material.hpp:105-125 */
@@ -332,6 +334,10 @@ static int mat_shading(const orc_scene* s, orc_rng* g, const orc_mat* m, const r
         if (nz3(m->d + 4) && rnd(g) < 0.5) {       /* specular lobe: wo is NOT set */
             *att = V(m->d[4], m->d[5], m->d[6]);
             *spec = 1;
+            if (s->compat_fixed) {                  /* fixed: a mirror reflection */
+                *wo = mkray(x->pos, reflect(vnorm(wi->d), x->normal), wi->time, wi->t_min, wi->t_max);
+                if (!(vdot(wo->d, x->normal) > 0)) return 0;
+            }
             return 1;
         }
         if (nz3(m->d + 10)) {
@@ -342,13 +348,14 @@ static int mat_shading(const orc_scene* s, orc_rng* g, const orc_mat* m, const r
         }
         *spec = 0;                                  /* diffuse lobe: wo is NOT set */
         *att = base;
+        if (s->compat_fixed) *wo = mkray(x->pos, cosine_sample(g, x->normal), wi->time, wi->t_min, wi->t_max);   /* fixed: cosine lobe */
         return 1;
     }
     }
     return 0;
 }
 
-static double mat_pdf(orc_rng* g, const orc_mat* m, const isect* x, const ray* wo)
+static double mat_pdf(orc_rng* g, const orc_mat* m, const isect* x, const ray* wo, int fixed)
 {
     switch (m->kind) {
     case ORC_MAT_LAMBERTIAN: {                                           /* material.hpp:37-41 */
@@ -361,7 +368,7 @@ static double mat_pdf(orc_rng* g, const orc_mat* m, const isect* x, const ray* w
     }
     case ORC_MAT_PHONG: {                                                /* material.hpp:257-266 */
         double c = vdot(x->normal, vnorm(wo->d));
-        if (nz3(m->d + 4) && rnd(g) < 0.5) return c > ORC_EPS ? 1 : 0;
+        if (!fixed && nz3(m->d + 4) && rnd(g) < 0.5) return c > ORC_EPS ? 1 : 0;   /* fixed: the diffuse lobe's pdf, no second roll */
         return c > 0 ? c / ORC_PI : 0;
     }
     default: return 0.0;                                                 /* material.hpp:14 (dielectric, emissive) */
@@ -1502,13 +1509,25 @@ static v3 trace(orc_scene* s, orc_rng* g, const ray* wi, int depth, uint64_t* ra
     v3 emission = mat_emit(s, m, &x);
     if (!mat_shading(s, g, m, wi, &x, &wo, &att, &spec)) return emission;
 
+    if (s->compat_fixed) {
+        /* No counterpart in the reference ("compat=fixed"): the same estimator with three defects repaired.  A specular
+         * lobe is a delta: its weight is the attenuation (the reference divides by material::pdf, which is 0 for a dielectric and for a
+         * metal reflection below the surface: 0 * inf).  phong sets wo (mat_shading above).  A diffuse direction of zero probability
+         * contributes nothing instead of 0/0. */
+        if (spec) return vadd(emission, vmul(att, trace(s, g, &wo, depth - 1, rays)));
+        if (rnd(g) < 0.5) wo = mkray(x.pos, lights_rand(s, g, x.pos), wi->time, wi->t_min, wi->t_max);
+        mpdf = mat_pdf(g, m, &x, &wo, 1);
+        pdf = 0.5 * (lights_pdf(s, x.pos, wo.d) + mpdf);
+        if (!(pdf > 0) || !(mpdf > 0)) return emission;
+        return vadd(emission, sdiv(vmul(smul(mpdf, att), trace(s, g, &wo, depth - 1, rays)), pdf));
+    }
     if (spec) {
-        mpdf = mat_pdf(g, m, &x, &wo);
+        mpdf = mat_pdf(g, m, &x, &wo, 0);
         pdf = mpdf;
     }
     else {
         if (rnd(g) < 0.5) wo = mkray(x.pos, lights_rand(s, g, x.pos), wi->time, wi->t_min, wi->t_max);
-        mpdf = mat_pdf(g, m, &x, &wo);
+        mpdf = mat_pdf(g, m, &x, &wo, 0);
         pdf = 0.5 * (lights_pdf(s, x.pos, wo.d) + mpdf);
     }
     if (s->early_exit) {
@@ -1623,6 +1642,7 @@ int orc_debug_path(orc_scene* s, int i, int j, int k, uint64_t seed, int max_dep
 }
 
 void orc_set_early_exit(orc_scene* s, int on) { s->early_exit = on; }
+void orc_set_compat_fixed(orc_scene* s, int on) { s->compat_fixed = on; }
 
 /* ------------------------------------------------------------------ rng fills */
 void orc_glibc_rand_fill(unsigned seed, int n, int32_t* out)
@@ -1697,7 +1717,7 @@ void orc_unit_mat(int n, const double* in, double* out)
             const orc_mat* m = &s->mats[mats[q]];
             v3 em = mat_emit(s, m, &x);
             int sc = mat_shading(s, &g, m, &wi, &x, &wo, &att, &spec);
-            double pdf = sc ? mat_pdf(&g, m, &x, &wo) : 0.0;
+            double pdf = sc ? mat_pdf(&g, m, &x, &wo, 0) : 0.0;
             double* w = out + ((size_t) q * n + i) * 12;
             w[0] = sc; w[1] = spec; w[2] = pdf;
             put3(w + 3, em);

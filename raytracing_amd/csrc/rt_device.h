@@ -845,8 +845,10 @@ template <typename R, int kMat = 0> __device__ inline vec3<R> mat_emit(const Mat
 // with some flag combinations lanes on the dielectric branch came out with o.z and time of the scattered ray holding
 // temporaries of the other branches (found by comparing per-pixel ray counts with the fp64 mode; guarded by
 // tests/test_gpu_parity.py::test_fast_ray_counts_match_fp64_per_pixel).
+// `fixed` (RT_FLAG_COMPAT_FIXED, no counterpart in the reference): phong sets its direction (mirror / cosine lobe), and a specular
+// direction below the surface is absorbed (returns false) instead of continuing with a pdf of 0.
 template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
-                                                         vec3<R>& dir, bool& dir_set, vec3<R>& att, bool& spec)
+                                                         vec3<R>& dir, bool& dir_set, vec3<R>& att, bool& spec, bool fixed = false)
 {
     dir_set = true;
     switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
@@ -861,6 +863,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         dir = next + fuzz;
         att = texc;
         spec = true;
+        if (fixed && !(dot(dir, h.normal) > R(0))) return false;
         return true;
     }
     case RT_MAT_DIELECTRIC:                                                                 // material.hpp:105-125
@@ -879,7 +882,8 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
             att = vec3<R>(m.d[4], m.d[5], m.d[6]);
             spec = true;
-            dir_set = false;
+            dir_set = fixed;
+            if (fixed) { dir = reflect(normalize(wi.d), h.normal); if (!(dot(dir, h.normal) > R(0))) return false; }
             return true;
         }
         if (nz3(m.d + 10)) {
@@ -890,7 +894,8 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         }
         spec = false;
         att = base;
-        dir_set = false;
+        dir_set = fixed;
+        if (fixed) dir = cosine_sample(g, h.normal);
         return true;
     }
     default: return false;                                                                  // emissive material.hpp:156-159
@@ -941,17 +946,17 @@ template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, c
 }
 #else
 template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, const Mat<R>& m, const Ray<R>& wi, const Hit<R>& h, const vec3<R>& texc,
-                                                                       Ray<R>& wo, vec3<R>& att, bool& spec)
+                                                                       Ray<R>& wo, vec3<R>& att, bool& spec, bool fixed = false)
 {
     vec3<R> dir;
     bool dir_set = false;
-    if (!mat_scatter<R, kMat>(g, m, wi, h, texc, dir, dir_set, att, spec)) return false;
+    if (!mat_scatter<R, kMat>(g, m, wi, h, texc, dir, dir_set, att, spec, fixed)) return false;
     if (dir_set) { wo.o = h.pos; wo.from = h.id; wo.d = dir; wo.time = wi.time; }
     return true;
 }
 #endif
 
-template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo)
+template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo, bool fixed = false)
 {
     switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN: {                                                               // material.hpp:37-41
@@ -964,7 +969,7 @@ template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Ma
     }
     case RT_MAT_PHONG: {                                                                    // material.hpp:257-266
         R c = dot(h.normal, normalize(wo.d));
-        if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);
+        if (!fixed && nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);   // fixed: the diffuse lobe's pdf, no second roll
         return c > R(0) ? c / consts<R>::pi : R(0);
     }
     default: return R(0);                                                                   // material.hpp:14
@@ -1188,8 +1193,21 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
                 vec3<R> att;
                 bool spec = false;
                 L += beta * emission;
-                if (mat_shading(g, m, ray, h, texc, wo, att, spec)) {
+                const bool fixed = (a.flags & RT_FLAG_COMPAT_FIXED) != 0;
+                if (mat_shading(g, m, ray, h, texc, wo, att, spec, fixed)) {
                     R pdf, mpdf;
+                    bool dropped = false;
+                    if (fixed) {                                                            // no counterpart in the reference: see rtcore.h RT_FLAG_COMPAT_FIXED
+                        if (spec) beta = beta * att;                                        // a delta lobe weighs its attenuation
+                        else {
+                            if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                            mpdf = mat_pdf(g, m, h, wo, true);
+                            pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                            if (!(pdf > R(0)) || !(mpdf > R(0))) dropped = true;            // a direction of zero probability contributes nothing
+                            else beta = beta * ((R(1) / pdf) * (mpdf * att));
+                        }
+                    }
+                    else {
                     if (spec) {                                                             // raytracing.cpp:51-54
                         mpdf = mat_pdf(g, m, h, wo);
                         pdf = mpdf;
@@ -1203,10 +1221,13 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 4 ? RT_WAVES_FP32 : 1)) ren
                     vec3<R> w = mpdf * att;
                     if (!rt_finite(inv) || !rt_finite(w.x) || !rt_finite(w.y) || !rt_finite(w.z)) poisoned = true;
                     beta = beta * (inv * w);
-                    ray = wo;
-                    depth--;
-                    done = depth <= 0;
-                    if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
+                    }
+                    if (!dropped) {
+                        ray = wo;
+                        depth--;
+                        done = depth <= 0;
+                        if (poisoned && (a.flags & RT_FLAG_EARLY_EXIT)) done = true;
+                    }
                 }
             }
             if (done) {

@@ -293,20 +293,28 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                 Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
                 vec3<R> att;
                 bool spec = false;
-                if (mat_shading<R, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec)) {
+                const bool fixed = (a.flags & RT_FLAG_COMPAT_FIXED) != 0;
+                if (mat_shading<R, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec, fixed)) {
                     R pdf, mpdf;
-                    if (spec) {                                                             // raytracing.cpp:51-54
-                        mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
-                        pdf = mpdf;
-                    }
-                    else {                                                                  // raytracing.cpp:55-61
-                        if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
-                        mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
-                        pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
-                    }
-                    R inv = R(1) / pdf;                                                     // raytracing.cpp:69, vec3.hpp:121-123
-                    vec3<R> w = mpdf * att;
-                    beta = beta * (inv * w);
+                    bool dropped = false;
+                    if (!(fixed && spec)) {
+                        if (spec) {                                                         // raytracing.cpp:51-54
+                            mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
+                            pdf = mpdf;
+                        }
+                        else {                                                              // raytracing.cpp:55-61
+                            if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+                            mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo, fixed);
+                            pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                        }
+                        // RT_FLAG_COMPAT_FIXED: a direction of zero probability contributes nothing (the reference forms 0 * inf)
+                        if (fixed && (!(pdf > R(0)) || !(mpdf > R(0)))) dropped = true;
+                        R inv = R(1) / pdf;                                                 // raytracing.cpp:69, vec3.hpp:121-123
+                        vec3<R> w = mpdf * att;
+                        att = inv * w;
+                    }                                                                       // RT_FLAG_COMPAT_FIXED: a delta lobe weighs its attenuation
+                    if (!dropped) {
+                    beta = beta * att;
                     // a non-finite 1/pdf or weight (also 0 * inf) poisons the sample whatever follows: the recursion multiplies it in
                     if (!rt_finite(beta.x) || !rt_finite(beta.y) || !rt_finite(beta.z)) poisoned = true;
                     ray = wo;
@@ -320,6 +328,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     // components made it a diagonal ray that walked the whole tree: mesh workload 152 -> 69 ms per 64 spp.
                     // (Spheres answer such a ray with NaN roots: the other variants walk on.)
                     if (kFull >= 3 && !done && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) { zero_ray = true; done = true; path_rays++; }
+                    }
                 }
                 else L = beta * emission;                                                   // the path ends on an emitter (or absorber)
             }

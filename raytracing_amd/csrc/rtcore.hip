@@ -613,6 +613,8 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     if ((p->flags & RT_FLAG_WAVEFRONT) && p->max_depth > 65535) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT keeps the depth in 16 bits: max_depth <= 65535");
     if ((long long) p->width * p->height >= (1LL << 31) / 3) return fail(RT_EINVAL, "image too large");
     if (p->mode != RT_MODE_REFERENCE_FP64 && p->mode != RT_MODE_FAST_FP32 && p->mode != RT_MODE_FP32_REFERENCE_TREE && p->mode != RT_MODE_FAST_FP64) return fail(RT_EINVAL, "unknown mode");
+    if ((p->flags & RT_FLAG_COMPAT_FIXED) && ((p->flags & (RT_FLAG_QUEUE | RT_FLAG_WAVEFRONT)) || s->queue || (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_LEGACY_LOOP))))
+        return fail(RT_EINVAL, "RT_FLAG_COMPAT_FIXED is implemented by the wave kernel and the reference-order kernels only");
     if (p->mode == RT_MODE_FAST_FP64 && (p->flags & (RT_FLAG_LEGACY_LOOP | RT_FLAG_WAVEFRONT)))
         return fail(RT_EINVAL, "RT_MODE_FAST_FP64 runs the wave kernel only: RT_FLAG_LEGACY_LOOP and RT_FLAG_WAVEFRONT are fp32 A/B variants");
     if (s->n_lights <= 0)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(HERE, "librtcore.so")   # RTCORE_LIB: A/B builds of the same library (tools/)
 
 MODE_REFERENCE_FP64, MODE_FAST_FP32, MODE_FP32_REFERENCE_TREE, MODE_FAST_FP64 = 0, 1, 2, 3
-FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_LEGACY_LOOP, FLAG_WAVEFRONT, FLAG_QUEUE = 1, 2, 4, 8, 16, 32, 64
+FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_LEGACY_LOOP, FLAG_WAVEFRONT, FLAG_QUEUE, FLAG_COMPAT_FIXED = 1, 2, 4, 8, 16, 32, 64, 128
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 NOALLOC_MAX_RAYS = 32768
 

@@ -226,6 +226,9 @@ class Scene:
     def set_early_exit(self, on):
         lib().orc_set_early_exit(self.h, int(on))
 
+    def set_compat_fixed(self, on):
+        lib().orc_set_compat_fixed(self.h, int(on))
+
     def render(self, spp_begin, spp_end, max_depth, rng_mode=RNG_COUNTER, seed=0, n_threads=1, want_rgb=True):
         w, h = self.width, self.height
         total = np.zeros((h, w, 3))

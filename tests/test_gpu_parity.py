@@ -653,3 +653,58 @@ def test_all_feature_test_lit_radiance_fast_modes_vs_reference_mode(R):
         assert got <= 1.25 * floor, (mode, got, floor)
         assert abs(c.mean() - a.mean()) <= 0.02 * a.mean(), (mode, c.mean(), a.mean())
     sc.destroy(); hs.free()
+
+
+@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "obj", "cornell"])
+def test_compat_fixed_matches_the_oracles_restatement(R, golden_dir, name):
+    """RT_FLAG_COMPAT_FIXED has no counterpart in the reference: specular lobes weigh as deltas, phong sets wo, a
+    zero-probability direction contributes nothing.  The oracle restates the same rules (orc_set_compat_fixed); on the same streams
+    the fp64 modes must follow it like they follow the reference rules: <= 1e-9 relative on >= 99 % of the pixels, ray counts within
+    0.2 %; the two fp64 modes equal each other to 1e-13 where neither coincident surfaces (obj, cornell) nor a moving sphere directly
+    under scene::build_bvh (`mixed`) let the tree decide; the fp32
+    fast mode within 5 % relative RMSE apart from <= 3 fireflies.  And the repair shows: glass and metal no longer reject their samples
+    (c0: 8 % of the samples rejected under the reference rules), OBJ scenes no longer lose the half of their samples phong left
+    without a direction."""
+    tag, make = SCENES[name]
+    g, m = load(golden_dir, name)
+    osc = make(golden_dir, m)
+    w, h, spp, depth = m["width"], m["height"], 8, min(m["depth"], 24)
+    _, _, cnt_ref = osc.render(0, spp, depth, O.RNG_COUNTER, seed=11, n_threads=8)
+    osc.set_compat_fixed(1)
+    want, want_rgb, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=11, n_threads=8)
+    assert int(cnt[1]) <= 0.02 * w * h * spp, "hardly a sample is rejected any more"
+    if name in ("c0_seed1", "obj"):
+        assert int(cnt_ref[1]) >= 0.05 * w * h * spp
+    sc = R.Scene(osc.export())
+    frames = {}
+    for mode in (R.MODE_REFERENCE_FP64, R.MODE_FAST_FP64):
+        got, rgb, st = sc.render_to_host(w, h, 0, spp, depth, mode, seed=11, flags=R.FLAG_COMPAT_FIXED)
+        frames[mode] = got
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+        if not (name == "mixed" and mode == R.MODE_FAST_FP64):         # the reference's time-0 msphere box: see the first-hit test
+            # coincident surfaces (the fixture OBJ's glass tetrahedron stands IN the floor plane, a Cornell box's bottom face lies in the
+            # floor): the hit at identical t is the visit order's, and under these rules both candidates carry light, so the fast tree
+            # may shade a handful of pixels differently (measured: 24 of 3072)
+            ties = 0.02 if (mode == R.MODE_FAST_FP64 and name in ("obj", "cornell")) else 0.01
+            assert float((rel.max(axis=2) > 1e-9).mean()) < ties, (mode, float((rel.max(axis=2) > 1e-9).mean()))
+            # the fast tree does not imitate the reference walk's answer to a NaN ray (every test "passes"): such paths end earlier there,
+            # as in test_render_fast_fp64_equals_reference_mode -- ray totals within 0.5 %, never the image
+            tol = 0.005 if mode == R.MODE_FAST_FP64 else 0.002
+            assert abs(st["rays"] - int(cnt[0])) <= tol * int(cnt[0]) + 8, (mode, st["rays"], int(cnt[0]))
+            assert abs(st["rejected"] - int(cnt[1])) <= 0.01 * int(cnt[1]) + 8
+    if name == "c0_seed1":                                               # no coincident surfaces, no top-level moving sphere
+        a, b = frames[R.MODE_REFERENCE_FP64], frames[R.MODE_FAST_FP64]
+        assert float((np.abs(a - b) / np.maximum(np.abs(a), 1e-3)).max()) <= 1e-13
+    got32, _, st32 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=11, flags=R.FLAG_COMPAT_FIXED)
+    g32 = got32.astype(np.float64)
+    same_tree = frames[R.MODE_FAST_FP64]                                 # the fp32 mode walks the same tree: same answer at coincident surfaces
+    err = np.sqrt(((g32 - same_tree) ** 2).sum(axis=2))
+    fire = err > np.sqrt(np.mean(same_tree ** 2))
+    # where two surfaces coincide, fp32 rounding of t decides ray by ray which one wins (z-fighting under the tetrahedron): up to 8 such
+    # pixels on the scenes that have coincident surfaces, 3 fireflies elsewhere
+    assert int(fire.sum()) <= (8 if name in ("obj", "cornell") else 3) and np.isfinite(g32).all(), np.argwhere(fire)
+    assert float(np.sqrt(np.mean((g32[~fire] - same_tree[~fire]) ** 2)) / np.sqrt(np.mean(same_tree ** 2))) < 0.05
+    with pytest.raises(R.RtError, match="COMPAT_FIXED"):
+        sc.render_to_host(w, h, 0, 1, depth, R.MODE_FAST_FP64, seed=11, flags=R.FLAG_COMPAT_FIXED | R.FLAG_QUEUE)
+    sc.destroy()
+    osc.free()
