@@ -298,7 +298,7 @@ def main():
         time_at_peak = rays_per_launch * (flop32 / (PEAK_FP32_TFLOPS * 1e12) + flop64 / (PEAK_FP64_TFLOPS * 1e12))
         peak_mix = rays_per_launch * flop_per_ray / time_at_peak / 1e12
         valu_frac = time_at_peak / secs
-        # OBJ-loader scenes (triangles + phong only) walk the 32-byte quantised nodes by default (rtcore.hip, RT_QNODES overrides)
+        # OBJ-loader scenes (triangles + phong only) walk the quantised four-wide nodes by default (rtcore.hip, RT_QNODES overrides)
         quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and fast
         node_bytes = (32.0 if quantised else 64.0) if fast else (56.0 if is_fp64 else 32.0)
         leaf_bytes = 96.0 if is_fp64 else 48.0

@@ -219,7 +219,7 @@ int rt_first_hit_fast(rt_scene* scene, const double* rays, size_t n_rays, int32_
 
 /* Closest hit of the same rays through the fast tree with the render kernels' own culling code: fp64 != 0 is RT_MODE_FAST_FP64's
  * traversal (primitive, t bits and frontward flag must equal rt_first_hit's), fp64 == 0 RT_MODE_FAST_FP32's (t widened to double).
- * Walks the 32-byte quantised nodes when the scene's renders do.  No counterpart in the reference.  Synchronous. */
+ * Walks the quantised four-wide nodes when the scene's renders do.  No counterpart in the reference.  Synchronous. */
 int rt_first_hit_tree(rt_scene* scene, const double* rays, size_t n_rays, int fp64, int32_t* prim, double* t, int32_t* front);
 
 /* Device-buffer helpers for hosts that do not otherwise touch HIP (the C++ driver). */

@@ -171,15 +171,80 @@ public:
     static const int RT_BUILD_SAH_DEPTH = 40;   // below this depth fall back to median splits: bounds the traversal stack
 };
 
-// One axis of a 32-byte quantised node (rt_device.h QNode, decoded in rt_wave.h slab_quant): lo[c] / hi[c] are the two children's
-// planes, already padded by the kernel's fp32 decode error.  word = a float origin <= both lo whose low byte is the signed exponent e
-// of the step 2^e (the kernel uses the whole dword as the origin, so the origin must stay below the boxes whatever that byte
-// holds); q = bytes left lo, right lo, left hi, right hi in steps from the origin, lo rounded down and hi up.
-inline void quantise_axis(const double lo[2], const double hi[2], uint32_t& word, uint32_t& q)
+// ---- quantised four-wide nodes (rt_device.h WNode): the binary tree collapsed.  A wide node starts from a binary node's two children and, while it
+// has fewer than four, replaces its inner child of the largest surface area by that child's two children.
+struct WideNode { Box box[4]; int32_t child[4]; int n = 0; };
+struct WideTree {
+    std::vector<WideNode> nodes;
+    int stack_need = 0;           // most entries a traversal can hold: a visit pushes up to n - 1 children
+};
+
+// bin_need[i]: stack entries the binary subtree under node i needs when walked as it is (one push per level).  `budget`: entries the
+// wide subtree may use; a child is only expanded while every child's binary subtree still fits what the extra push leaves, so
+// the tallest paths of the tree stay narrower and need <= budget holds by construction (given budget >= bin_need of the root).
+inline int32_t widen_node(const Tree& t, const std::vector<int>& bin_need, int32_t bin, int budget, WideTree& out, int& need)
 {
-    const double mn = std::min(lo[0], lo[1]), mx = std::max(hi[0], hi[1]);
-    // origin: a float <= mn whatever its low byte holds (the kernel reads the exponent byte as part of the origin).  Setting
-    // low bits moves a negative float down and a positive one up, so a positive origin starts one 256-ulp step lower.
+    WideNode w;
+    const Node& b = t.nodes[bin];
+    auto need_of = [&](int32_t code) { return code >= 0 ? bin_need[code] : 0; };
+    w.box[0] = b.lbox; w.child[0] = b.left; w.n = 1;
+    if (!(b.left == b.right && b.left < 0)) { w.box[1] = b.rbox; w.child[1] = b.right; w.n = 2; }     // a single-leaf tree names its leaf twice
+    while (w.n >= 2 && w.n < 4) {
+        int others = 0;                                    // the tallest child that stays as it is, per candidate computed below
+        int pick = -1; double area = -1;
+        for (int k = 0; k < w.n; k++) {
+            if (w.child[k] < 0 || w.box[k].area() <= area) continue;
+            const Node& c = t.nodes[w.child[k]];
+            others = std::max(need_of(c.left), need_of(c.right));
+            for (int j = 0; j < w.n; j++) if (j != k) others = std::max(others, need_of(w.child[j]));
+            if (others + w.n > budget) continue;           // w.n + 1 children push up to w.n entries
+            area = w.box[k].area(); pick = k;
+        }
+        if (pick < 0) break;
+        const Node& c = t.nodes[w.child[pick]];
+        w.box[pick] = c.lbox; w.child[pick] = c.left;
+        w.box[w.n] = c.rbox; w.child[w.n] = c.right; w.n++;
+    }
+    const int32_t idx = (int32_t) out.nodes.size();
+    out.nodes.push_back(w);
+    int deepest = 0;
+    for (int k = 0; k < w.n; k++)
+        if (w.child[k] >= 0) {
+            int sub = 0;
+            const int32_t c = widen_node(t, bin_need, w.child[k], budget - (w.n - 1), out, sub);
+            out.nodes[idx].child[k] = c;
+            deepest = std::max(deepest, sub);
+        }
+    need = deepest + w.n - 1;
+    return idx;
+}
+
+inline WideTree widen(const Tree& t, int budget)
+{
+    WideTree w;
+    if (t.nodes.empty()) return w;
+    // children follow their parent in Tree::nodes (split() reserves the parent's slot first): one backward pass
+    std::vector<int> bin_need(t.nodes.size(), 0);
+    for (size_t i = t.nodes.size(); i-- > 0;) {
+        const Node& n = t.nodes[i];
+        bin_need[i] = 1 + std::max(n.left >= 0 ? bin_need[n.left] : 0, n.right >= 0 ? bin_need[n.right] : 0);
+    }
+    w.nodes.reserve(t.nodes.size() / 2 + 1);
+    widen_node(t, bin_need, 0, std::max(budget, bin_need[0]), w, w.stack_need);
+    return w;
+}
+
+// One axis of a wide node (decoded in rt_wave.h slab_wide): lo[k] / hi[k] are the children's planes, already padded by the kernel's
+// fp32 decode error.  word = a float origin <= all lo whose low byte is the signed exponent e of the step 2^e (the kernel uses the
+// whole dword as the origin, so the origin must stay below the boxes whatever that byte holds); qlo / qhi: byte k = child k's low /
+// high plane in steps from the origin, lo rounded down and hi up; slots k >= n hold lo 255, hi 0 (the kernel masks them by their
+// child code).
+inline void quantise_axis_wide(const double* lo, const double* hi, int n, uint32_t& word, uint32_t& qlo, uint32_t& qhi)
+{
+    double mn = lo[0], mx = hi[0];
+    for (int k = 1; k < n; k++) { mn = std::min(mn, lo[k]); mx = std::max(mx, hi[k]); }
+    // origin: a float <= mn whatever its low byte holds.  Setting low bits moves a negative float down and a positive one up, so a
+    // positive origin starts one 256-ulp step lower.
     float f = (float) mn; if ((double) f > mn) f = std::nextafterf(f, -INFINITY);
     uint32_t bits; std::memcpy(&bits, &f, 4);
     if (bits & 0x80000000u) { if (bits & 0xffu) bits = (bits | 0xffu) + 1u; }       // negative: magnitude up to the next multiple of 256 ulp
@@ -193,11 +258,14 @@ inline void quantise_axis(const double lo[2], const double hi[2], uint32_t& word
     e = std::min(127, std::max(-126, e));
     word = bits | (uint32_t) (e & 0xff);
     const double origin = as_float(word), step = std::ldexp(1.0, e);
-    q = 0;
-    for (int c = 0; c < 2; c++) {   // bytes: left lo, right lo, left hi, right hi
-        const double ql = std::floor((lo[c] - origin) / step), qh = std::ceil((hi[c] - origin) / step);
-        const uint32_t l8 = (uint32_t) std::min(255.0, std::max(0.0, ql)), h8 = (uint32_t) std::min(255.0, std::max(0.0, qh));
-        q |= (l8 << (8 * c)) | (h8 << (16 + 8 * c));
+    qlo = 0; qhi = 0;
+    for (int k = 0; k < 4; k++) {
+        uint32_t l8 = 255, h8 = 0;
+        if (k < n) {
+            l8 = (uint32_t) std::min(255.0, std::max(0.0, std::floor((lo[k] - origin) / step)));
+            h8 = (uint32_t) std::min(255.0, std::max(0.0, std::ceil((hi[k] - origin) / step)));
+        }
+        qlo |= l8 << (8 * k); qhi |= h8 << (8 * k);
     }
 }
 

@@ -78,18 +78,20 @@ struct alignas(16) BNode {
     int32_t left, right;
     int32_t pad[2];
 };
-// The same node in 32 B (two 16-byte loads instead of four): the vector-memory address path is the busiest unit of the
-// traversal on meshes (~18 TA cycles per load instruction, PMC TA_TA_BUSY ~80 %), so halving the loads per node visit pays
-// for the decode.  Per axis a: o[a] = a float origin <= both boxes' minima whose low byte is the (signed) exponent e of a
-// power-of-two step -- the kernel uses the whole dword as the origin, exponent bits included, and the builder accounts for
-// them; q[a] = four bytes: left lo, right lo, left hi, right hi in steps from the origin (lo rounded down, hi up, after
-// padding by the fp32 decode error, so the decoded boxes contain the real ones).  lo <= hi byte-wise, so which plane a ray
-// meets first follows from the sign of its direction alone: a ray going down the axis rotates the dword by 16 bits and reads
-// near planes from bytes 0-1, far planes from bytes 2-3 -- no min / max per plane pair.
-struct alignas(16) QNode {
+// Quantised four-wide node (64 B): the binary tree collapsed (rt_bvh_build.h widen()), so a traversal makes half as many dependent
+// round trips to memory and LDS (mesh workload: 8.8 node visits per ray instead of 16.6, 18.1 box tests instead of 17.2).
+// Per axis a: o[a] = a float origin <= all children's minima whose low byte is the (signed) exponent e of a power-of-two step -- the
+// kernel uses the whole dword as the origin, exponent bits included, and the builder accounts for them; lo[a] / hi[a]: byte k = child
+// k's low / high plane in steps from the origin (lo rounded down, hi up, after padding by the fp32 decode error, so the decoded boxes
+// contain the real ones).  lo <= hi byte-wise, so which plane a ray meets first follows from the sign of its direction alone: the
+// near planes are lo[a] for a ray going up the axis, else hi[a] -- no min / max per plane pair.  child[k]: child code as in BNode, or
+// RT_BVH_SENTINEL for an unused slot; n: children in use (2..4; 1 for a single-leaf tree).
+struct alignas(16) WNode {
     uint32_t o[3];
-    uint32_t q[3];
-    int32_t left, right;
+    uint32_t lo[3];
+    uint32_t hi[3];
+    int32_t child[4];
+    uint32_t n, pad[2];
 };
 #define RT_Q_SLOTS_MAX 256          // rt_queue.h: path slots per wave (list entries are one byte)
 #define RT_BVH_SENTINEL ((int32_t) 0x80000000)
@@ -120,7 +122,7 @@ template <typename R> struct Scene {
     const Prim<R>* lights; const TriShade<R>* light_tris; int32_t n_lights;
     int32_t need_uv;                  // some material reads uv (image texture)
     const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
-    const QNode* qnodes;              // the same tree, 32-byte quantised nodes
+    const WNode* wnodes; int32_t wide_stack;   // the same tree collapsed to quantised four-wide nodes; stack entries a traversal of it can need
     const Xform<R>* xforms;           // instance transforms (null: none)
     Camera<R> cam;
     __host__ __device__ Side<R> side() const { Side<R> s; s.tris = tris; s.xforms = xforms; return s; }
@@ -1058,7 +1060,7 @@ struct RenderArgs {
     // lanes holding paths; stay in the node loop while lanes on inner nodes >= node_keep/256 of the traversing lanes;
     // regenerate when at least regen_min lanes have no path (or none has one)
     uint32_t trav_keep, node_keep, regen_min;
-    uint32_t quantised;                        // fast mode walks Scene::qnodes instead of Scene::bnodes
+    uint32_t quantised;                        // fast mode walks Scene::wnodes (quantised, four-wide) instead of Scene::bnodes
     uint32_t kinds;                            // fast kernel variant: 0 spheres / rects / triangles only, 1 also boxes or volumes, 2 also instances, 3 triangles + phong only
     uint32_t xcd_tiles;                        // != 0: rt_wave.h deals 8 x 8-tile super-tiles to the 8 XCDs (grid padded to whole rounds of 8 super-tiles)
     // rt_queue.h (decoupled traversal / shading): slots per wave (0: the rt_wave.h kernel), pools allocated, lanes that must wait before a

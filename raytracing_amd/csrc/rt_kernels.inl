@@ -84,19 +84,8 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
         if (a.kinds == 2) return launch_wave<RT_REAL, false, 2>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 1) return launch_wave<RT_REAL, false, 1>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 3) {
-            if (sizeof(RT_REAL) == sizeof(double)) {
-                if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
-                return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);
-            }
-#ifdef RT_WITH_FAST_BVH
-            // fp32: the lean variant runs RT_WAVES_OBJ workgroups per CU when their LDS fits (32-byte nodes are its default) ...
-            if (lds * RT_WAVES_OBJ <= 160 * 1024) {
-                if (a.quantised) return launch_wave<float, true, 3>(count, grid, lds, s, sc, a, accum, counters);
-                return launch_wave<float, false, 3>(count, grid, lds, s, sc, a, accum, counters);
-            }
-            // ... a deeper tree: the same code at the other variants' occupancy
-            if (!a.quantised) return launch_wave<float, false, 4>(count, grid, lds, s, sc, a, accum, counters);
-#endif
+            if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
+            return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);
         }
         if (a.quantised) return launch_wave<RT_REAL, true, 0>(count, grid, lds, s, sc, a, accum, counters);
         return launch_wave<RT_REAL, false, 0>(count, grid, lds, s, sc, a, accum, counters);
@@ -138,7 +127,7 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 hipError_t launch_first_hit_tree(const Scene<RT_REAL>& sc, const double* rays, int n, int quantised, int32_t* prim, RT_REAL* t, int32_t* front, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    const size_t stack_bytes = (size_t) (sc.bvh_depth + 2) * 256 * sizeof(uint32_t);
+    const size_t stack_bytes = (size_t) ((quantised ? sc.wide_stack : sc.bvh_depth) + 2) * 256 * sizeof(uint32_t);
     if (stack_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&first_hit_tree_kernel<RT_REAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) stack_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&first_hit_tree_kernel<RT_REAL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) stack_bytes);

@@ -110,7 +110,6 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
     };
     const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
     const float t_min = consts<float>::tmin;
-    const BNode* __restrict__ nodes = sc.bnodes;
     const Prim<R>* __restrict__ fprims = sc.fprims;
     const int node_keep = (int) a.node_keep, handoff_min = (int) a.q_handoff_min, shade_starved = (int) a.q_shade_starved;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -301,33 +300,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                 for (;;) {
                     const int n_inner = __popcll(__ballot(tv.cur >= 0));
                     if (n_inner == 0 || n_inner * 256 < n_trav * node_keep) break;
-                    if (tv.cur >= 0) {
-                        float tl, tr; bool hl, hr;
-                        int32_t c_left, c_right;
-                        if (kQuant) {
-                            const QNode n = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
-                            slab_quant<R>(n, tv, t_min, tl, hl, tr, hr);
-                            c_left = n.left; c_right = n.right;
-                        }
-                        else {
-                            const BNode n = *at32(nodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
-                            slab_fma<R>(n.lb, tv, t_min, tl, hl);
-                            slab_fma<R>(n.rb, tv, t_min, tr, hr);
-                            c_left = n.left; c_right = n.right;
-                        }
-                        if (kCount && first_active_lane()) vs.w_node++;
-                        if (kCount) vs.n_box += 2;
-                        if (hl && hr) {
-                            const bool left_first = tl <= tr;
-                            const int32_t far = left_first ? c_right : c_left;
-                            tv.cur = left_first ? c_left : c_right;
-                            tv.sp += 1024u;
-                            stack_at(tv.sp) = (uint32_t) far;
-                        }
-                        else if (hl) tv.cur = c_left;
-                        else if (hr) tv.cur = c_right;
-                        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
-                    }
+                    if (tv.cur >= 0) node_step<R, kQuant, kCount>(sc, tv, t_min, stack_at, vs);
                 }
                 lap(1);
                 if (tv.cur < 0 && tv.cur != RT_BVH_SENTINEL) {

@@ -22,15 +22,15 @@
 #pragma once
 
 #include "rt_device.h"
+// Waves per SIMD the variants are compiled for.  With the four-wide nodes a visit holds 16 node dwords and 24 plane distances, and
+// the OBJ-loader variants pay for registers rather than for occupancy: mesh workload, 4K, 64 spp, fp32 60.0 ms at 4 waves (128
+// VGPRs), 59.3 at 3; fp64 (rays, leaf tests and shading in double) 89.2 ms at 4, 82.9 at 3 (168 VGPRs), 105.8 at 2.  (Binary
+// 32-byte nodes, round 2 before the wide nodes: fp32 best at 5 waves / 96 VGPRs, fp64 at 4.)
 #ifndef RT_WAVES_OBJ
-#define RT_WAVES_OBJ 5    // waves per SIMD of the OBJ-loader variant (96 VGPRs): measured 4 waves +11 % time, 6 waves +4 %; the other variants lose at 5
+#define RT_WAVES_OBJ 4
 #endif
-// waves per SIMD of the R = double variants.  Unconstrained the OBJ-loader variant takes 208 VGPRs (2 waves) and the node loop -- the
-// same fp32 code as in the float kernel, 70 % of the wave time -- starves for latency hiding: mesh workload at 4K, 8 spp: 40.7 ms at
-// 2 waves, 31.6 at 3, 28.7 at 4 (276 B of scratch per lane, none of it in the node loop: the fp64 triangle test reloads the ray, the
-// shading body spills), 28.0 at 5 (needs a tree <= 23 deep to fit five workgroups' LDS; not taken).  Sphere scenes: 111.6 / 91.4 / 94.2.
 #ifndef RT_WAVES_FP64_OBJ
-#define RT_WAVES_FP64_OBJ 4
+#define RT_WAVES_FP64_OBJ 3
 #endif
 #ifndef RT_WAVES_FP64
 #define RT_WAVES_FP64 3
@@ -95,23 +95,73 @@ template <typename T> __device__ inline const T* at32(const T* base, uint32_t by
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
 }
 
-// both children of a quantised node (rt_device.h QNode): per axis t = q * (step * idir) + (origin * idir - o * idir), near planes in
-// bytes 0-1 and far planes in bytes 2-3 once the dword is rotated for the ray's direction (Trav::rot)
-template <typename R> __device__ inline void slab_quant(const QNode& n, const Trav& t, float t_min, float& tl, bool& hl, float& tr, bool& hr)
+// all four children of a wide node (rt_device.h WNode): the near planes are the low bytes for a ray going up the axis, else the high ones
+template <typename R> __device__ inline void slab_wide(const WNode& n, const Trav& t, float t_min, float tn[4], bool h[4])
 {
-    float ln[3], rn[3], lf[3], rf[3];
+    float nr[3][4], fr[3][4];
     const float idir[3] = { t.idir.x, t.idir.y, t.idir.z }, noid[3] = { t.noid.x, t.noid.y, t.noid.z };
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float A = ldexpf(idir[a], (int) (int8_t) (n.o[a] & 0xffu)), B = fmaf(__uint_as_float(n.o[a]), idir[a], noid[a]);
-        const uint32_t q = __builtin_amdgcn_alignbit(n.q[a], n.q[a], t.rot >> (8 * a));      // the hardware reads 5 bits of the shift: 0 or 16
-        ln[a] = fmaf(float(q & 0xffu), A, B); rn[a] = fmaf(float((q >> 8) & 0xffu), A, B);
-        lf[a] = fmaf(float((q >> 16) & 0xffu), A, B); rf[a] = fmaf(float(q >> 24), A, B);
+        const bool down = ((t.rot >> (8 * a)) & 16u) != 0u;
+        const uint32_t qn = down ? n.hi[a] : n.lo[a], qf = down ? n.lo[a] : n.hi[a];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { nr[a][k] = fmaf(float((qn >> (8 * k)) & 0xffu), A, B); fr[a][k] = fmaf(float((qf >> (8 * k)) & 0xffu), A, B); }
     }
-    const float tnl = fmaxf(fmaxf(ln[0], ln[1]), fmaxf(ln[2], t_min)), tfl = fminf(fminf(lf[0], lf[1]), fminf(lf[2], t.closest));
-    const float tnr = fmaxf(fmaxf(rn[0], rn[1]), fmaxf(rn[2], t_min)), tfr = fminf(fminf(rf[0], rf[1]), fminf(rf[2], t.closest));
-    tl = tnl; hl = tnl <= fmaf(tfl, cull_slack<R>::rel, t.slack);
-    tr = tnr; hr = tnr <= fmaf(tfr, cull_slack<R>::rel, t.slack);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float near = fmaxf(fmaxf(nr[0][k], nr[1][k]), fmaxf(nr[2][k], t_min)), far = fminf(fminf(fr[0][k], fr[1][k]), fminf(fr[2][k], t.closest));
+        tn[k] = near;
+        h[k] = near <= fmaf(far, cull_slack<R>::rel, t.slack) && n.child[k] != RT_BVH_SENTINEL;
+    }
+}
+
+// One node visit of one lane: test the children's boxes, go on with the nearest one hit and push the others (farthest first), or
+// pop.  kQuant: four-wide quantised nodes (WNode), else the binary fp32 nodes (BNode).  stack_at(address) names an LDS stack entry.
+template <typename R, bool kQuant, bool kCount, typename StackAt>
+__device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, StackAt&& stack_at, VisitStats& vs)
+{
+    if constexpr (kQuant) {
+        const WNode n = *at32(sc.wnodes, (uint32_t) tv.cur * (uint32_t) sizeof(WNode));
+        float t4[4]; bool h4[4];
+        slab_wide<R>(n, tv, t_min, t4, h4);
+        if (kCount && first_active_lane()) vs.w_node++;
+        if (kCount) vs.n_box += n.n;
+        int32_t c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c4[k] = n.child[k]; if (!h4[k]) t4[k] = __builtin_inff(); }
+        // nearest first: a five-exchange network over (distance, child); a child that was missed sorts last
+        auto order = [&](int i, int j) {
+            const bool sw = t4[j] < t4[i];
+            const float ti = sw ? t4[j] : t4[i], tj = sw ? t4[i] : t4[j];
+            const int32_t ci = sw ? c4[j] : c4[i], cj = sw ? c4[i] : c4[j];
+            t4[i] = ti; t4[j] = tj; c4[i] = ci; c4[j] = cj;
+        };
+        order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+        if (t4[3] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[3]; }
+        if (t4[2] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[2]; }
+        if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
+        if (t4[0] < __builtin_inff()) tv.cur = c4[0];
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+    }
+    else {
+        const BNode n = *at32(sc.bnodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
+        float tl, tr; bool hl, hr;
+        slab_fma<R>(n.lb, tv, t_min, tl, hl);
+        slab_fma<R>(n.rb, tv, t_min, tr, hr);
+        if (kCount && first_active_lane()) vs.w_node++;
+        if (kCount) vs.n_box += 2;
+        if (hl && hr) {
+            const bool left_first = tl <= tr;
+            const int32_t far = left_first ? n.right : n.left;
+            tv.cur = left_first ? n.left : n.right;
+            tv.sp += 1024u;
+            stack_at(tv.sp) = (uint32_t) far;
+        }
+        else if (hl) tv.cur = n.left;
+        else if (hr) tv.cur = n.right;
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+    }
 }
 
 template <typename R, bool kCount, bool kQuant, int kFull>
@@ -154,7 +204,6 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     };
     const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
     const float t_min = consts<float>::tmin;          // box culling; primitive tests take consts<R>::tmin
-    const BNode* __restrict__ nodes = sc.bnodes;
     const Prim<R>* __restrict__ fprims = sc.fprims;
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
 
@@ -226,33 +275,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     const unsigned c2 = (unsigned) __popcll(__ballot(!alive));
                     census[0] += c0; census[1] += c1; census[2] += c2;
                 }
-                if (tv.cur >= 0) {
-                    float tl, tr; bool hl, hr;
-                    int32_t c_left, c_right;
-                    if (kQuant) {
-                        const QNode n = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
-                        slab_quant<R>(n, tv, t_min, tl, hl, tr, hr);
-                        c_left = n.left; c_right = n.right;
-                    }
-                    else {
-                        const BNode n = *at32(nodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
-                        slab_fma<R>(n.lb, tv, t_min, tl, hl);
-                        slab_fma<R>(n.rb, tv, t_min, tr, hr);
-                        c_left = n.left; c_right = n.right;
-                    }
-                    if (kCount && first_active_lane()) vs.w_node++;
-                    if (kCount) vs.n_box += 2;
-                    if (hl && hr) {
-                        const bool left_first = tl <= tr;
-                        const int32_t far = left_first ? c_right : c_left;
-                        tv.cur = left_first ? c_left : c_right;
-                        tv.sp += 1024u;
-                        stack_at(tv.sp) = (uint32_t) far;
-                    }
-                    else if (hl) tv.cur = c_left;
-                    else if (hr) tv.cur = c_right;
-                    else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
-                }
+                if (tv.cur >= 0) node_step<R, kQuant, kCount>(sc, tv, t_min, stack_at, vs);
             }
             lap(1);
             // leaves
@@ -382,7 +405,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     }
 }
 
-// Closest hit of explicit rays through the fast tree, with the render kernel's own culling code (trav_begin, slab_fma / slab_quant,
+// Closest hit of explicit rays through the fast tree, with the render kernel's own culling code (trav_begin, node_step: slab_fma / slab_wide,
 // LDS stack) and primitive tests: test hook behind rt_first_hit_tree.  R = double must return the reference walk's primitive, t bits
 // and frontward flag (the closest hit does not depend on the tree), which is what pins RT_MODE_FAST_FP64's traversal.
 template <typename R, bool kQuant>
@@ -403,33 +426,10 @@ __global__ void __launch_bounds__(256) first_hit_tree_kernel(Scene<R> sc, const 
     r.time = R(p[6]);
     const float t_min = consts<float>::tmin;
     Trav tv; Closest<R> best;
+    VisitStats unused;
     trav_begin(tv, best, r, stack_base);
     while (tv.cur != RT_BVH_SENTINEL) {
-        if (tv.cur >= 0) {
-            float tl, tr; bool hl, hr;
-            int32_t c_left, c_right;
-            if (kQuant) {
-                const QNode nd = *at32(sc.qnodes, (uint32_t) tv.cur * (uint32_t) sizeof(QNode));
-                slab_quant<R>(nd, tv, t_min, tl, hl, tr, hr);
-                c_left = nd.left; c_right = nd.right;
-            }
-            else {
-                const BNode nd = *at32(sc.bnodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
-                slab_fma<R>(nd.lb, tv, t_min, tl, hl);
-                slab_fma<R>(nd.rb, tv, t_min, tr, hr);
-                c_left = nd.left; c_right = nd.right;
-            }
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                const int32_t far = left_first ? c_right : c_left;
-                tv.cur = left_first ? c_left : c_right;
-                tv.sp += 1024u;
-                stack_at(tv.sp) = (uint32_t) far;
-            }
-            else if (hl) tv.cur = c_left;
-            else if (hr) tv.cur = c_right;
-            else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
-        }
+        if (tv.cur >= 0) node_step<R, kQuant, false>(sc, tv, t_min, stack_at, unused);
         else {
             const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
             for (int k = 0; k < count; k++) {

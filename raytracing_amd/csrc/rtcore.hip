@@ -119,7 +119,7 @@ struct rt_scene {
     uint32_t wf_slots = 2u << 20;             // RT_WF_SLOTS overrides
     uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;
     uint32_t xcd_tiles = 0;                   // super-tiles dealt to the XCDs (rt_wave.h): on when tree + records exceed one XCD's L2; RT_XCD_TILES overrides
-    uint32_t quantised = 0;                   // fast mode walks the 32-byte nodes (RT_QNODES overrides)   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
+    uint32_t quantised = 0;                   // fast mode walks the quantised four-wide nodes (RT_QNODES overrides)   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
@@ -320,7 +320,7 @@ template <typename R> int build_fast_tree(const rt_scene_desc*, const Flat&, con
 // records in its leaf order.  Node arrays stay owned by the fp32 scene.
 template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<double>>& prims, DeviceScene<double>& out, const DeviceScene<float>* tree)
 {
-    out.view.bnodes = nullptr; out.view.qnodes = nullptr; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
+    out.view.bnodes = nullptr; out.view.wnodes = nullptr; out.view.wide_stack = 0; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
     if (!tree || !tree->view.bnodes) return RT_OK;
     if (tree->leaf_order.size() * sizeof(rt::Prim<double>) >= (1ull << 32))
         return fail(RT_EUNSUPPORTED, "fast-mode fp64 record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");
@@ -328,7 +328,7 @@ template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const
     for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree->leaf_order[i]];
     int rc;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
-    out.view.bnodes = tree->view.bnodes; out.view.qnodes = tree->view.qnodes; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
+    out.view.bnodes = tree->view.bnodes; out.view.wnodes = tree->view.wnodes; out.view.wide_stack = tree->view.wide_stack; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
     return RT_OK;
 }
 template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, const std::vector<rt::Prim<float>>& prims, DeviceScene<float>& out, const DeviceScene<float>*)
@@ -348,8 +348,8 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
             if (p >= 0 && d->prim_kind[p] == RT_PRIM_VOLUME && seen[p]++ > 0) items.push_back(items[p]);
     }
     // cost of a primitive test relative to a node step, measured (4K sweeps): triangles 1.0 (mesh workload -2.8 % time against 1.5),
-    // scenes with spheres 1.5 (their test solves the quadratic in fp64).  Depth limit 26: a stack of 28 levels is the deepest with
-    // which five workgroups share a CU's LDS (rt_wave.h, RT_WAVES_OBJ); the 5.2 M-triangle mesh came out deeper and ran at four.
+    // scenes with spheres 1.5 (their test solves the quadratic in fp64).  Depth limit 26: from the binary 32-byte nodes of round 2
+    // (a 28-level stack was the deepest with which five workgroups shared a CU's LDS); kept, lower limits cost time (22: +4 %).
     bool all_triangles = true;
     for (int i = 0; i < d->n_prims; i++) all_triangles &= d->prim_kind[i] == RT_PRIM_TRIANGLE;
     // SAH bins per axis: 64 for triangle meshes (-5 % frame time against 16 on the 0.3 / 1.3 / 5.2 M-triangle meshes alike; 128 and more
@@ -373,28 +373,36 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         }
         nodes[i].left = tree.nodes[i].left; nodes[i].right = tree.nodes[i].right;
     }
-    // 32-byte quantised twin of every node (rt_device.h QNode): decoded boxes must contain the fp32 boxes above
+    // the same tree collapsed to quantised four-wide nodes (rt_device.h WNode): decoded boxes must contain the fp32 boxes above
     double radius = 0;
     for (const rt::BNode& n : nodes) for (int k = 0; k < 6; k++) { if (std::isfinite(n.lb[k])) radius = std::max(radius, (double) std::fabs(n.lb[k])); if (std::isfinite(n.rb[k])) radius = std::max(radius, (double) std::fabs(n.rb[k])); }
     const double pad = 8 * 1.2e-7 * std::max(radius, 1e-30);       // fp32 decode error of origin*idir - o*idir, in world units
-    std::vector<rt::QNode> qn(nodes.size());
-    for (size_t i = 0; i < nodes.size(); i++) {
-        const rt::BNode& n = nodes[i];
+    // stack budget 35: 37 levels of LDS stack are what four fp32 workgroups (three fp64 ones) per CU leave room for; the mesh workload's
+    // tree (binary depth 24) collapses freely into 34.  A tighter budget keeps the tallest paths narrower: 30 -> 38 % more nodes, +5 % time
+    int budget = 35;
+    if (const char* e = std::getenv("RT_WIDE_STACK")) budget = std::max(1, std::atoi(e));
+    const rtb::WideTree wt = rtb::widen(tree, budget);
+    std::vector<rt::WNode> wn(wt.nodes.size());
+    for (size_t i = 0; i < wn.size(); i++) {
+        const rtb::WideNode& w = wt.nodes[i];
+        std::memset(&wn[i], 0, sizeof(rt::WNode));
         for (int a = 0; a < 3; a++) {
-            const double lo[2] = { (double) n.lb[a] - pad, (double) n.rb[a] - pad }, hi[2] = { (double) n.lb[3 + a] + pad, (double) n.rb[3 + a] + pad };
-            uint32_t word, q;
-            rtb::quantise_axis(lo, hi, word, q);
-            qn[i].o[a] = word;
-            qn[i].q[a] = q;
+            double lo[4], hi[4];
+            for (int k = 0; k < w.n; k++) { lo[k] = (double) down(w.box[k].lo[a]) - pad; hi[k] = (double) up(w.box[k].hi[a]) + pad; }
+            rtb::quantise_axis_wide(lo, hi, w.n, wn[i].o[a], wn[i].lo[a], wn[i].hi[a]);
         }
-        qn[i].left = n.left; qn[i].right = n.right;
+        for (int k = 0; k < 4; k++) wn[i].child[k] = k < w.n ? w.child[k] : RT_BVH_SENTINEL;
+        wn[i].n = (uint32_t) w.n;
     }
+    if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree: %zu nodes of 64 B, stack need %d entries\n", wn.size(), wt.stack_need);
+    if (wt.stack_need + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode wide tree needs a deeper traversal stack than RT_BVH_STACK_MAX");
     std::vector<rt::Prim<float>> ordered(tree.order.size());
     for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree.order[i]];
     out.leaf_order.assign(tree.order.begin(), tree.order.end());
     int rc;
     if ((rc = upload(out.owned, nodes, &out.view.bnodes))) return rc;
-    if ((rc = upload(out.owned, qn, &out.view.qnodes))) return rc;
+    if ((rc = upload(out.owned, wn, &out.view.wnodes))) return rc;
+    out.view.wide_stack = wt.stack_need;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
     out.view.n_bnodes = (int32_t) nodes.size();
     out.view.bvh_depth = tree.depth;
@@ -570,8 +578,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     // measured optima (tools/sweep_wave.py, 4K): small scenes spend as much time shading as traversing and want fuller shading
     // passes (64/64); big meshes are traversal-bound and want fuller node steps (96/128)
     if (desc->n_prims < 4096) { s->trav_keep = 64; s->node_keep = 64; }
-    // 32-byte nodes trade vector-L1 line lookups (two loads per node instead of four) for decode arithmetic: a gain only where
-    // the kernel has arithmetic to spare, the lean OBJ-loader variant at 5 waves/SIMD (mesh workload -4 % time, 5.2 M triangles -2.5 %)
+    // quantised four-wide nodes halve the dependent node visits of a ray for ~5 % more box tests: mesh workload -6 % time (fp32), -9 %
+    // (fp64), 5.2 M triangles -9 % (fp64); 485 spheres: no gain (boxes loosened by the quantisation cost what the fewer visits save)
     s->quantised = s->only_triangles;
     if (const char* env = std::getenv("RT_QNODES")) s->quantised = std::atoi(env) != 0;
     // measured at 4K: 1.3 M triangles -1.4 % time, 5.2 M triangles -2.3 %; 485 spheres (everything L1/L2-resident anyway) +1..4 %
@@ -663,8 +671,11 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         q_pools = s->q_pools[k]; q_locks = s->q_locks[k];
         a.q_slots = s->q_slots; a.q_pools = s->q_n_pools; a.q_handoff_min = s->q_handoff_min; a.q_shade_starved = s->q_shade_starved;
     }
+    if (q_pools && a.kinds == 0) a.quantised = 0;              // the decoupled kernel's generic variant walks the binary nodes only
+    // the kernels launch_render gives the wide nodes to (rt_kernels.inl): wave and decoupled kernel of the variants 0 and 3
+    const bool wide = a.quantised != 0 && (a.kinds == 0 || a.kinds == 3) && !(p->flags & RT_FLAG_LEGACY_LOOP);
     if (p->mode == RT_MODE_FAST_FP64) {
-        a.bvh_stack_levels = (uint32_t) s->d64.view.bvh_depth + 2;
+        a.bvh_stack_levels = (uint32_t) (wide ? s->d64.view.wide_stack : s->d64.view.bvh_depth) + 2;
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st, q_pools, q_locks));
     }
     else if (p->mode == RT_MODE_REFERENCE_FP64) {
@@ -672,7 +683,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
     }
     else {
-        if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) s->d32.view.bvh_depth + 2;
+        if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) (wide ? s->d32.view.wide_stack : s->d32.view.bvh_depth) + 2;
         else if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
         HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st, q_pools, q_locks));
     }

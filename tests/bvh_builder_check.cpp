@@ -1,5 +1,6 @@
 // tests/bvh_builder_check.cpp -- host-side check of the fast mode's SAH builder (raytracing_amd/csrc/rt_bvh_build.h), built and run by
-// tests/test_bvh_builder.py.  usage: bvh_builder_check <n_items> <depth_limit> <bins> <leaf_max> ; prints one line of key=value pairs.
+// tests/test_bvh_builder.py.  usage: bvh_builder_check <n_items> <depth_limit> <bins> <leaf_max> [wide_stack_budget] ; prints one line of key=value pairs.
+// The w_* keys describe the tree collapsed to four-wide nodes (rtb::widen).
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -55,7 +56,40 @@ int main(int argc, char** argv)
     long missing = 0, repeated = 0, unreachable = 0;
     for (int v : seen_prim) { missing += v == 0; repeated += v > 1; }
     for (int v : seen_node) unreachable += v == 0;
-    std::printf("n=%d nodes=%zu depth=%d walked_depth=%d missing=%ld repeated=%ld unreachable=%ld shared=%ld bad_box=%ld bad_leaf=%ld\n", n, t.nodes.size(),
+    std::printf("n=%d nodes=%zu depth=%d walked_depth=%d missing=%ld repeated=%ld unreachable=%ld shared=%ld bad_box=%ld bad_leaf=%ld", n, t.nodes.size(),
                 t.depth, max_depth, missing, repeated, unreachable, shared, bad_box, bad_leaf);
+
+    // the same tree in four-wide nodes: still a partition, every stored box contains what hangs below it, and no traversal order can
+    // hold more stack entries than the tree reports (a visit pushes at most n - 1 children)
+    const int budget = argc > 5 ? std::atoi(argv[5]) : 35;
+    const rtb::WideTree w = rtb::widen(t, budget);
+    std::vector<int> w_prim(n, 0), w_node(w.nodes.size(), 0);
+    long w_bad_box = 0, w_shared = 0, w_bad_n = 0, w_full = 0;
+    int w_worst_stack = 0;
+    std::function<rtb::Box(int32_t, int)> wwalk = [&](int32_t c, int on_stack) {
+        rtb::Box b;
+        if (c < 0) {
+            const int code = ~c, first = code >> 3, count = (code & 7) + 1;
+            for (int k = 0; k < count; k++) { const int id = t.order[first + k]; w_prim[id]++; b.grow(original[id].box); }
+            return b;
+        }
+        if (w_node[c]++) { w_shared++; return b; }
+        const rtb::WideNode& nd = w.nodes[c];
+        if (nd.n < 1 || nd.n > 4 || (nd.n == 1 && n != 1)) w_bad_n++;
+        w_full += nd.n == 4;
+        if (on_stack + nd.n - 1 > w_worst_stack) w_worst_stack = on_stack + nd.n - 1;
+        for (int k = 0; k < nd.n; k++) {
+            const rtb::Box sub = wwalk(nd.child[k], on_stack + nd.n - 1);      // worst case: every sibling still waits on the stack
+            if (!inside(nd.box[k], sub)) w_bad_box++;
+            b.grow(nd.box[k]);
+        }
+        return b;
+    };
+    if (!w.nodes.empty()) wwalk(0, 0);
+    long w_missing = 0, w_repeated = 0, w_unreachable = 0;
+    for (int v : w_prim) { w_missing += v == 0; w_repeated += v > 1; }
+    for (int v : w_node) w_unreachable += v == 0;
+    std::printf(" w_nodes=%zu w_full=%ld w_stack=%d w_worst_stack=%d w_missing=%ld w_repeated=%ld w_unreachable=%ld w_shared=%ld w_bad_box=%ld w_bad_n=%ld\n",
+                w.nodes.size(), w_full, w.stack_need, w_worst_stack, w_missing, w_repeated, w_unreachable, w_shared, w_bad_box, w_bad_n);
     return 0;
 }

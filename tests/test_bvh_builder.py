@@ -17,8 +17,8 @@ def harness(tmp_path_factory):
     return exe
 
 
-def run(exe, n, limit, bins, leaf_max):
-    out = subprocess.check_output([exe, str(n), str(limit), str(bins), str(leaf_max)], text=True)
+def run(exe, n, limit, bins, leaf_max, budget=35):
+    out = subprocess.check_output([exe, str(n), str(limit), str(bins), str(leaf_max), str(budget)], text=True)
     return {k: int(v) for k, v in (kv.split("=") for kv in out.split())}
 
 
@@ -38,6 +38,22 @@ def test_tree_is_a_partition_with_containing_boxes_within_the_depth_limit(harnes
     assert r["depth"] <= limit, r
 
 
+@pytest.mark.parametrize("n,limit,budget", [(1, 26, 35), (2, 26, 35), (3, 26, 35), (5, 26, 35), (1000, 26, 35), (200000, 26, 35), (200000, 26, 26),
+                                            (200000, 18, 17), (200000, 26, 5), (50000, 40, 35)])
+def test_wide_tree_is_the_same_partition_within_its_stack_budget(harness, n, limit, budget):
+    """rtb::widen, the collapse to four-wide nodes: every primitive still sits in exactly one leaf, every wide node is reached once,
+    every box a node stores contains what hangs below it, nodes hold 2..4 children, and no traversal -- whatever order it visits
+    children in, with every unvisited sibling waiting on the stack -- holds more entries than the tree reports.  The report respects
+    the budget wherever the binary tree does (a budget below the binary tree's own need leaves the tallest paths binary)."""
+    r = run(harness, n, limit, 64, 4, budget)
+    assert r["w_missing"] == 0 and r["w_repeated"] == 0 and r["w_unreachable"] == 0 and r["w_shared"] == 0
+    assert r["w_bad_box"] == 0 and r["w_bad_n"] == 0
+    assert r["w_worst_stack"] <= r["w_stack"]
+    assert r["w_stack"] <= max(budget, r["depth"] - 1), r
+    if n >= 1000 and budget >= 35:
+        assert r["w_nodes"] * 3 < r["nodes"] * 2 and r["w_full"] * 3 > r["w_nodes"], r          # it does collapse (single-triangle leaves cannot be opened)
+
+
 def test_impossible_limit_falls_back_to_the_stack_maximum(harness):
     r = run(harness, 200000, 10, 16, 4)        # 2^10 leaves of 4 cannot hold 200 000 primitives
     assert r["missing"] == 0 and r["repeated"] == 0 and r["bad_box"] == 0
@@ -45,12 +61,13 @@ def test_impossible_limit_falls_back_to_the_stack_maximum(harness):
 
 
 def test_quantised_axis_contains_its_boxes(tmp_path):
-    """rtb::quantise_axis, the encoder of the 32-byte nodes: over magnitudes 0 ... 1e12, box sizes 0 ... 1e4, both signs, boxes that
-    straddle zero and degenerate ones, the planes the kernel decodes (whole dword as the origin -- exponent byte included -- plus a
-    byte offset times 2^e) contain both children's planes, lo <= hi byte-wise (what lets a ray pick the near plane by the sign of
-    its direction alone), no plane is clipped at 255, and none is looser than one step beyond what the origin's low byte gives away."""
+    """rtb::quantise_axis_wide, the encoder of the quantised four-wide nodes: over magnitudes 0 ... 1e12, box sizes 0 ... 1e4, both
+    signs, one to four children, boxes that straddle zero and degenerate ones, the planes the kernel decodes (whole dword as the
+    origin -- exponent byte included -- plus a byte offset times 2^e) contain every child's planes, lo <= hi byte-wise (what lets a
+    ray pick the near plane by the sign of its direction alone), no plane is clipped at 255, none is looser than one step beyond
+    what the origin's low byte gives away, and unused slots hold the inverted box."""
     exe = str(tmp_path / "qnode_check")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", CSRC, "-o", exe, os.path.join(HERE, "qnode_check.cpp")])
     r = {k: int(v) for k, v in (kv.split("=") for kv in subprocess.check_output([exe], text=True).split())}
     assert r["cases"] > 30000
-    assert r["not_contained"] == 0 and r["disordered"] == 0 and r["clipped"] == 0 and r["loose"] == 0, r
+    assert r["not_contained"] == 0 and r["disordered"] == 0 and r["clipped"] == 0 and r["loose"] == 0 and r["bad_empty"] == 0, r

@@ -165,7 +165,7 @@ def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
 @pytest.mark.parametrize("name", ["c0_seed1", "c0_seed7", "mixed", "cornell", "obj", "ngon", "features", "smoke"])
 def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, monkeypatch, name, qnodes):
     """RT_MODE_FAST_FP64's traversal (rt_first_hit_tree: the library's SAH tree, fp32 box culling with the render kernel's own code,
-    64-byte and 32-byte quantised nodes, fp64 primitive tests in the reference's evaluation order) against the reference walk
+    binary 64-byte nodes and quantised four-wide nodes, fp64 primitive tests in the reference's evaluation order) against the reference walk
     (rt_first_hit, itself bit-exact against the fixtures of the real reference): primitive id, t BITS and frontward flag must be
     equal on every fixture ray.  Nothing is thresholded; the rays that may differ are of three kinds, each recognised exactly and
     counted:
@@ -381,7 +381,7 @@ def test_volume_reference_order_modes_share_streams_and_wavefront_refuses(R, gol
 
 
 def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
-    """RT_QNODES=1: the fast mode walks the 32-byte quantised twin of its tree (two vector loads per node instead of four).
+    """RT_QNODES=1: the fast mode walks its tree collapsed to quantised four-wide nodes (half the node visits).
     Decoded boxes contain the real ones, so closest hits -- and with the same RNG streams the frame -- do not change, except
     where a ray hits the shared edge of two triangles at the same t: the winner then depends on the visit order, which the
     inflated boxes may swap.  Bar: ray and rejected-sample counts within 0.1 %, relative RMSE of the sums < 1 %."""

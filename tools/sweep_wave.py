@@ -52,6 +52,7 @@ for tk, nk, rm in itertools.product(ints(args.trav), ints(args.node), ints(args.
         r = st["rays"]
         msg += (f"  {r / t / 1e3:.0f} Mrays/s | lane-eff shade {r / (64 * st['wave_bounces']):.2f} node {st['box_tests'] / 2 / (64 * max(st['wave_node_steps'], 1)):.2f} "
                 f"leaf {st['leaf_tests'] / (64 * max(st['wave_leaf_steps'], 1)):.2f}")
+        msg += f" | per ray: box {st['box_tests'] / r:.1f} leaf {st['leaf_tests'] / r:.2f} node steps/wave-ray {64 * st['wave_node_steps'] / r:.1f}"
         pt = st["phase_ticks"]
         if sum(pt):
             msg += " | wave time regen/node/leaf/shade " + "/".join(f"{100 * x / sum(pt):.0f}%" for x in pt)

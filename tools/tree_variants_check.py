@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-pixel ray counts of the fast mode over different builds of its tree: 64-byte vs 32-byte nodes, default vs squeezed depth.
+"""Per-pixel ray counts of the fast mode over different builds of its tree: binary 64-byte vs quantised four-wide nodes, default vs squeezed depth / stack budget.
 
     python tools/tree_variants_check.py [--tris 300000]
 
@@ -32,9 +32,9 @@ for name, kw in scenes.items():
     path = kw.pop("path")
     hs = HostScene.obj(path, w, h, 1, **kw)
     base = None
-    for label, env in (("64-byte nodes", {"RT_QNODES": "0"}), ("32-byte nodes", {"RT_QNODES": "1"}), ("32-byte, depth 20", {"RT_QNODES": "1", "RT_BVH_DEPTH": "20"}),
-                       ("32-byte, leaf 8", {"RT_QNODES": "1", "RT_BVH_LEAF": "8"})):
-        for k in ("RT_QNODES", "RT_BVH_DEPTH", "RT_BVH_LEAF"):
+    for label, env in (("64-byte nodes", {"RT_QNODES": "0"}), ("wide nodes", {"RT_QNODES": "1"}), ("wide, depth 20", {"RT_QNODES": "1", "RT_BVH_DEPTH": "20"}), ("wide, stack budget 22", {"RT_QNODES": "1", "RT_WIDE_STACK": "22"}),
+                       ("wide, leaf 8", {"RT_QNODES": "1", "RT_BVH_LEAF": "8"})):
+        for k in ("RT_QNODES", "RT_BVH_DEPTH", "RT_BVH_LEAF", "RT_WIDE_STACK"):
             os.environ.pop(k, None)
         os.environ.update(env)
         sc = hs.upload()
