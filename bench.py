@@ -300,12 +300,14 @@ def main():
         valu_frac = time_at_peak / secs
         # OBJ-loader scenes (triangles + phong only) walk the quantised four-wide nodes by default (rtcore.hip, RT_QNODES overrides)
         quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and fast
-        node_bytes = (32.0 if quantised else 64.0) if fast else (56.0 if is_fp64 else 32.0)
+        # a fast-mode node record is 64 B and holds its children's boxes: four quantised ones or two fp32 ones
+        node_bytes = 64.0 if fast else (56.0 if is_fp64 else 32.0)
+        boxes_per_node = (4 if quantised else 2) if fast else 1
         leaf_bytes = 96.0 if is_fp64 else 48.0
-        bytes_per_ray = (box_per_ray * node_bytes / 2 if fast else box_per_ray * node_bytes) + leaf_per_ray * leaf_bytes
+        bytes_per_ray = box_per_ray * node_bytes / boxes_per_node + leaf_per_ray * leaf_bytes
         fetch_gbs = rays_per_launch * bytes_per_ray / secs / 1e9
         d = host.desc.contents
-        scene_mb = (d.n_prims * node_bytes * 0.6 + d.n_prims * leaf_bytes) / 1e6      # ~0.6 SAH nodes per primitive + primitive records
+        scene_mb = (d.n_prims * node_bytes * 1.2 / boxes_per_node + d.n_prims * leaf_bytes) / 1e6      # ~0.6 binary SAH nodes per primitive (half as many wide ones) + primitive records
         # HBM-side bytes per launch: bytes per ray measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload and mode at reduced spp (profiles/hbm_traffic.json, written by
         # tools/hbm_traffic.py from a run of this same command under the profiler), scaled by this launch's ray count; null when no
@@ -329,7 +331,7 @@ def main():
                     "kernel": kernel_name, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
                     "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
                     "flop_per_ray": {"fp32": round(flop32, 1), "fp64": round(flop64, 1)}, "record_bytes_per_ray": round(bytes_per_ray, 1),
-                    "node_record_bytes": node_bytes, "leaf_record_bytes": leaf_bytes, "scene_MB": round(scene_mb, 1),
+                    "node_record_bytes": node_bytes, "boxes_per_node_record": boxes_per_node, "leaf_record_bytes": leaf_bytes, "scene_MB": round(scene_mb, 1),
                     "note": "No dense contraction (no MFMA) and no HBM stream: node and primitive records are served by L1/L2/Infinity Cache (hbm_frac = measured "
                             "memory-side bytes / time / 8 TB/s).  The roof that binds is VALU issue under wave64 divergence: frac = algorithmic flops "
                             "(24 per fp32 box test, 40 per leaf test, 150 per ray of shading; leaf + shading in the result precision) / kernel time, "

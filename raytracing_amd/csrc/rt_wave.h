@@ -36,6 +36,10 @@
 #define RT_WAVES_FP64 3
 #endif
 
+#ifndef RT_ASM_MARK
+#define RT_ASM_MARK(text)
+#endif
+
 namespace rt {
 
 struct Trav {                 // per-lane traversal state, kept across phases
@@ -122,6 +126,7 @@ template <typename R, bool kQuant, bool kCount, typename StackAt>
 __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, StackAt&& stack_at, VisitStats& vs)
 {
     if constexpr (kQuant) {
+        RT_ASM_MARK("; wide node_step begin");
         const WNode n = *at32(sc.wnodes, (uint32_t) tv.cur * (uint32_t) sizeof(WNode));
         float t4[4]; bool h4[4];
         slab_wide<R>(n, tv, t_min, t4, h4);
@@ -143,6 +148,7 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
         if (t4[0] < __builtin_inff()) tv.cur = c4[0];
         else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+        RT_ASM_MARK("; wide node_step end");
     }
     else {
         const BNode n = *at32(sc.bnodes, (uint32_t) tv.cur * (uint32_t) sizeof(BNode));
