@@ -322,6 +322,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
             bool done = true;
             if (tv.hit >= 0) {
                 Hit<R> h;
+                RT_ASM_MARK("; shade: record");
                 fill_record<R, kFull>(fprims[tv.hit], sc.side(), ray, closest_of(tv, best), sc.need_uv != 0, h);
                 const Mat<R>& m = sc.mats[h.mat];
                 const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
@@ -330,9 +331,11 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                 vec3<R> att;
                 bool spec = false;
                 const bool fixed = (a.flags & RT_FLAG_COMPAT_FIXED) != 0;
+                RT_ASM_MARK("; shade: scatter");
                 if (mat_shading<R, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec, fixed)) {
                     R pdf, mpdf;
                     bool dropped = false;
+                    RT_ASM_MARK("; shade: pdf");
                     if (!(fixed && spec)) {
                         if (spec) {                                                         // raytracing.cpp:51-54
                             mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                         vec3<R> w = mpdf * att;
                         att = inv * w;
                     }                                                                       // RT_FLAG_COMPAT_FIXED: a delta lobe weighs its attenuation
+                    RT_ASM_MARK("; shade: tail");
                     if (!dropped) {
                     beta = beta * att;
                     // a non-finite 1/pdf or weight (also 0 * inf) poisons the sample whatever follows: the recursion multiplies it in
@@ -382,6 +386,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
             }
             else trav_begin(tv, best, ray, stack_base);
         }
+        RT_ASM_MARK("; shade: end");
         wave_rays += (unsigned long long) __popcll(__ballot(zero_ray));
         if (kCount && zero_ray) vs.n_zero++;
         wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
