@@ -187,9 +187,17 @@ def main():
     # one rank per GPU (RCCL).  RT_BENCH_BACKEND=gloo is for rehearsing the N > 1 path on a box with fewer GPUs than ranks:
     # ranks then share devices and the reduce goes through the host
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    # RT_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): a process group of one, every collective of the N > 1 path issued
+    # all the same -- what a one-GPU box can rehearse of the RCCL branch
+    grouped = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST", "0") == "1"
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # stdout carries the JSON line and nothing else: the host mirror prints the reference's "[INFO] building bvh..." lines there and RCCL
+    # its version banner, so file descriptor 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -199,10 +207,6 @@ def main():
     mode = getattr(R, MODES[args.mode])
     is_fp64 = args.mode in ("fp64", "fp64ref")
     dtype = torch.float64 if is_fp64 else torch.float32
-    # the host mirror prints the reference's "[INFO] building bvh..." lines on stdout; keep stdout for the JSON line
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
     if args.workload == "random_spheres":
         host = HostScene.random_spheres(w, h, 1)
         workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
@@ -225,8 +229,6 @@ def main():
         workload = (f"BASELINE configs[2]: procedural OBJ mesh ({n_tri} triangles, diffuse/specular MTL + emissive quad) through the OBJ loader "
                     f"and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
     scene = host.upload()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
 
     # this rank's share of the frame's samples
     k0, k1 = sample_range(rank, world, spp) if args.split == "spp" else (0, spp)
@@ -242,14 +244,14 @@ def main():
             # reduced frame: clear them (render overwrites [y0, y1) itself)
             buf[:y0].zero_(); buf[y1:].zero_()
         st = scene.render(buf.data_ptr(), w, h, k0, k1, args.depth, step_mode, seed=1, stream=stream, y_begin=y0, y_end=y1)   # syncs, returns kernel stats
-        reduce_frame(buf, world, dst=0)
+        reduce_frame(buf, world, dst=0, force=grouped)
         if rank == 0:
             R.resolve(buf.data_ptr(), buf.dtype == torch.float64, w * h, spp, rgb.data_ptr(), stream=stream)
         return st
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -267,7 +269,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if grouped:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -375,11 +377,14 @@ def main():
             ref = cpu_reference(args, obj_path if args.workload != "random_spheres" else None)
             if ref:
                 out["cpu_reference"] = ref      # extra to the contract: the unmodified reference next to the multi-threaded port
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     scene.destroy()
     host.free()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

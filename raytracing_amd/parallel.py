@@ -24,9 +24,10 @@ def row_range(rank, world, height):
     return rank * height // world, (rank + 1) * height // world
 
 
-def reduce_frame(accum, world, dst=0):
-    """SUM-reduce the per-rank accumulation buffers onto `dst` (RCCL on GPUs, gloo in the CPU tests). In place."""
-    if world > 1:
+def reduce_frame(accum, world, dst=0, force=False):
+    """SUM-reduce the per-rank accumulation buffers onto `dst` (RCCL on GPUs, gloo in the CPU tests). In place.
+    `force`: issue the collective even in a group of one (rehearses the RCCL call on a one-GPU box)."""
+    if world > 1 or force:
         import torch.distributed as dist
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum

@@ -106,12 +106,14 @@ def test_config3_soup_with_png_textures_through_the_host_loader(R, tmp_path):
     sc.destroy(); osc.free(); hs.free()
 
 
-@pytest.mark.parametrize("level,env", [(5, {}), (5, {"RT_QNODES": "0"}), (5, {"RT_XCD_TILES": "1"}), (6, {"RT_XCD_TILES": "1", "RT_BVH_DEPTH": "19"})])
+@pytest.mark.parametrize("level,env", [(5, {}), (5, {"RT_QNODES": "0"}), (5, {"RT_XCD_TILES": "1"}), (6, {"RT_XCD_TILES": "1", "RT_BVH_DEPTH": "19"}),
+                                       (6, {"RT_WIDE_STACK": "18"})])
 def test_config2_mesh_at_tree_depths_the_bench_runs(R, tmp_path, monkeypatch, level, env):
     """The generated OBJ mesh of bench.py (diffuse + glossy MTL groups, floor, emissive quad) at 20 k / 82 k triangles through the host
     loader and the reference BVH builder, 96 x 54, against the oracle on the same streams -- with the kernel variants the 4K frame uses
     switched on explicitly (quantised four-wide nodes are the default for OBJ scenes; RT_XCD_TILES=1 forces the super-tile order that is
-    otherwise reserved for scenes beyond one L2; RT_BVH_DEPTH=19 squeezes the 82 k-triangle tree against the builder's depth limit).
+    otherwise reserved for scenes beyond one L2; RT_BVH_DEPTH=19 squeezes the 82 k-triangle tree against the builder's depth limit; RT_WIDE_STACK=18 squeezes the collapse to wide
+    nodes against its stack budget, so that the tallest paths of the tree stay binary).
     RT_MODE_FAST_FP64: <= 1e-9 relative on >= 99.5 % of the pixels, 8-bit frames equal but for <= 0.5 % of the values,
     ray counts within 0.2 %.  RT_MODE_FAST_FP32: relative RMSE over all pixels <= 5 %, at most 3 pixels off by more than the frame's rms
     radiance (a branch that flips under fp32 rounding can end a path on the lamp: one sample of up to 2^depth x emission), each of them
