@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
             lap(1);
             // leaves
             if (tv.cur < 0 && tv.cur != RT_BVH_SENTINEL) {
+                RT_ASM_MARK("; leaf step begin");
                 const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
                 for (int k = 0; k < count; k++) {
                     R t;
@@ -306,6 +307,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, &g)) { set_closest(tv, best, t); tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
+                RT_ASM_MARK("; leaf step end");
             }
             lap(2);
         }
