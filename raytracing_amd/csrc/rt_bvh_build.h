@@ -190,12 +190,11 @@ inline int32_t widen_node(const Tree& t, const std::vector<int>& bin_need, int32
     w.box[0] = b.lbox; w.child[0] = b.left; w.n = 1;
     if (!(b.left == b.right && b.left < 0)) { w.box[1] = b.rbox; w.child[1] = b.right; w.n = 2; }     // a single-leaf tree names its leaf twice
     while (w.n >= 2 && w.n < 4) {
-        int others = 0;                                    // the tallest child that stays as it is, per candidate computed below
         int pick = -1; double area = -1;
         for (int k = 0; k < w.n; k++) {
             if (w.child[k] < 0 || w.box[k].area() <= area) continue;
             const Node& c = t.nodes[w.child[k]];
-            others = std::max(need_of(c.left), need_of(c.right));
+            int others = std::max(need_of(c.left), need_of(c.right));     // the tallest binary subtree among the children there would be
             for (int j = 0; j < w.n; j++) if (j != k) others = std::max(others, need_of(w.child[j]));
             if (others + w.n > budget) continue;           // w.n + 1 children push up to w.n entries
             area = w.box[k].area(); pick = k;
