@@ -324,11 +324,26 @@ def main():
         except (OSError, ValueError):
             pass
         hbm_frac = round(traffic / secs / 1e9 / PEAK_HBM_GBS, 4) if traffic is not None else None
+        # unit utilisation of the same kernel from the latest PMC passes on file for this workload and mode (tools/collect_profiles.py):
+        # share of cycles the vector ALUs / the texture-address units are busy.  Stored, not measured by this run -- the line says so.
+        pmc = None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_wave_kernel_{args.mode}_{args.workload}_4k_16spp.json")))
+            if files and (w, h) == (3840, 2160):
+                with open(files[-1]) as f:
+                    derived = json.load(f).get("derived", {})
+                for name, v in derived.items():
+                    if ", false," in name:          # the timed kernel, not its counting twin
+                        pmc = {"valu_busy": round(v["valu_busy"], 3), "ta_busy": round(v["ta_busy"], 3),
+                               "source": f"profiles/{os.path.basename(files[-1])}: rocprofv3 --pmc passes of this command at 16 spp, not measured by this run"}
+        except (OSError, ValueError, KeyError):
+            pass
         kernel_name = {"fp64": "rt::render_wave_kernel<double>", "fp32": "rt::render_wave_kernel<float>", "fp32ref": "rt::render_kernel<float>",
                        "fp64ref": "rt::render_kernel<double>"}[args.mode]
         assert 0.0 < valu_frac <= 1.0, f"roofline fraction {valu_frac} outside (0, 1]: the cost model or the peak is wrong"
         roofline = {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": round(peak_mix, 1), "unit": "TFLOP/s", "frac": round(valu_frac, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "hbm_peak_GBs": PEAK_HBM_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "hbm_peak_GBs": PEAK_HBM_GBS, "pmc": pmc,
                     "l1_frac": round(fetch_gbs / PEAK_L1_GBS, 4), "l1_achieved_GBs": round(fetch_gbs, 1), "l1_peak_GBs": round(PEAK_L1_GBS, 0),
                     "kernel": kernel_name, "kernel_ms_avg": round(avg_ms, 3), "rays_per_launch": int(rays_per_launch),
                     "box_tests_per_ray": round(box_per_ray, 2), "leaf_tests_per_ray": round(leaf_per_ray, 2),
