@@ -199,7 +199,8 @@ int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int sp
 /* Parity / debug entry: closest hit of explicit rays (origin[3], direction[3], time; t_min 1e-3, t_max inf as
  * ray.hpp:12-13) through scene.objects.intersect (group.hpp:68-83 -> bvh.hpp:58-68), fp64, reference visit order.
  * Outputs (host, any may be NULL): primitive id or -1, t, frontward flag, number of box tests, number of leaf
- * tests, FNV-1a hash of the visited pre-order entry indices.  Synchronous. */
+ * tests, FNV-1a hash of the visited pre-order entry indices.  Synchronous.  Like rt_render, the first-hit entry points need the
+ * scene's device to be the current one (RT_EINVAL otherwise). */
 int rt_first_hit(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
                  uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);
 

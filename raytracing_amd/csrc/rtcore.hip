@@ -736,6 +736,7 @@ int rt_frame_reduce(void* dst_dev, int dst_device, void* const* src_dev, const i
 {
     if (!dst_dev || n_src < 0 || (n_src && (!src_dev || !src_device))) return fail(RT_EINVAL, "dst_dev and n_src source buffers with their devices are required");
     if (n_src == 0 || n_values == 0) return RT_OK;
+    if (n_values > (size_t) 0x7fffffff * 256) return fail(RT_EINVAL, "rt_frame_reduce: buffer too large");
     const size_t bytes = n_values * (accum_is_fp64 ? 8 : 4);
     int current = -1;
     HIP_TRY(hipGetDevice(&current));
@@ -793,12 +794,22 @@ int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int sp
     return RT_OK;
 }
 
+// the first-hit entry points stage their rays on the current device and launch there: the scene must live on it (as rt_render requires)
+static int require_scene_device(const rt_scene* s)
+{
+    int current = -1;
+    HIP_TRY(hipGetDevice(&current));
+    if (current != s->device) return fail(RT_EINVAL, "the scene lives on device " + std::to_string(s->device) + " but device " + std::to_string(current) + " is current: call rt_device_set first");
+    return RT_OK;
+}
+
 int rt_first_hit(rt_scene* s, const double* rays, size_t n, int32_t* prim, double* t, int32_t* front, uint32_t* n_box, uint32_t* n_leaf,
                  uint64_t* visit_hash)
 {
     if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
     if (n == 0) return RT_OK;
     if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    if (int rc_dev = require_scene_device(s)) return rc_dev;
     double* d_rays = nullptr; void* d_out = nullptr;
     const size_t per = 4 + 8 + 4 + 4 + 4 + 8;
     HIP_TRY(hipMalloc((void**) &d_rays, n * 7 * sizeof(double)));
@@ -867,6 +878,7 @@ int rt_first_hit_fast(rt_scene* s, const double* rays, size_t n, int32_t* prim, 
     if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
     if (n == 0) return RT_OK;
     if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    if (int rc_dev = require_scene_device(s)) return rc_dev;
     double* d_rays = nullptr; int32_t* d_prim = nullptr; float* d_t = nullptr;
     int rc = RT_OK;
     auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
@@ -887,6 +899,7 @@ int rt_first_hit_tree(rt_scene* s, const double* rays, size_t n, int fp64, int32
     if (!s || (!rays && n)) return fail(RT_EINVAL, "scene and rays are required");
     if (n == 0) return RT_OK;
     if (n > (size_t) 1 << 28) return fail(RT_EINVAL, "too many rays in one call");
+    if (int rc_dev = require_scene_device(s)) return rc_dev;
     double* d_rays = nullptr; int32_t* d_prim = nullptr; int32_t* d_front = nullptr; void* d_t = nullptr;
     int rc = RT_OK;
     auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
