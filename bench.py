@@ -335,7 +335,7 @@ def main():
                     derived = json.load(f).get("derived", {})
                 for name, v in derived.items():
                     if ", false," in name:          # the timed kernel, not its counting twin
-                        pmc = {"valu_busy": round(v["valu_busy"], 3), "ta_busy": round(v["ta_busy"], 3),
+                        pmc = {"valu_busy": round(v["valu_busy"], 3), "ta_busy": round(v["ta_busy"], 3), "waves_per_simd": round(v.get("waves_per_simd", 0.0), 2),
                                "source": f"profiles/{os.path.basename(files[-1])}: rocprofv3 --pmc passes of this command at 16 spp, not measured by this run"}
         except (OSError, ValueError, KeyError):
             pass

@@ -22,7 +22,9 @@ for k, v in sq["pmc"].items():
     if "GRBM_GUI_ACTIVE" in t:
         # the SQ / TA counters of a dispatch are sums over the 32 CUs of one XCD; GRBM_GUI_ACTIVE is that XCD's busy cycles
         derived[k] = {"valu_busy": v["SQ_ACTIVE_INST_VALU"] / (32 * t["GRBM_GUI_ACTIVE"]), "ta_busy": t["TA_TA_BUSY_sum"] / (32 * t["GRBM_GUI_ACTIVE"]),
-                      "valu_insts_per_vmem_read": v["SQ_INSTS_VALU"] / max(v["SQ_INSTS_VMEM_RD"], 1), "wait_share_of_wave_cycles": v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]}
+                      "valu_insts_per_vmem_read": v["SQ_INSTS_VALU"] / max(v["SQ_INSTS_VMEM_RD"], 1), "wait_share_of_wave_cycles": v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"],
+                      # SQ_WAVE_CYCLES counts resident waves in units of four cycles; 128 SIMDs per XCD
+                      "waves_per_simd": 4 * v["SQ_WAVE_CYCLES"] / (128 * t["GRBM_GUI_ACTIVE"])}
 json.dump({"command": "rocprofv3 --pmc ... -- python3 bench.py --spp 16 --steps 1 --warmup 0 --no-cpu --no-fp32 (RT_MODE_FAST_FP64, obj workload 4K)", "sq": sq, "ta": ta,
            "derived": derived}, open(os.path.join(dst, f"{tag}_pmc_wave_kernel_fp64_obj_4k_16spp.json"), "w"), indent=1)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), os.path.join(src, "pmc_fetch", "fetch_results.db"),
