@@ -1,4 +1,4 @@
-// raytracing_amd/csrc/rt_wave.h -- RT_MODE_FAST_FP32 render kernel: a per-wavefront state machine.
+// raytracing_amd/csrc/rt_wave.h -- render kernel of RT_MODE_FAST_FP64 and RT_MODE_FAST_FP32: a per-wavefront state machine.
 //
 // Replaces, for the fast mode, the lane-synchronous bounce loop of rt_device.h (one traversal to completion for all
 // 64 lanes, then one shading pass).  Measured on that loop (profiles/, tools/lane_efficiency.py): the traversal ran at
@@ -36,6 +36,8 @@
 #define RT_WAVES_FP64 3
 #endif
 
+// tools/node_step_isa.sh compiles with -DRT_ASM_MARK(text)=asm volatile(text) to find the node visit, the leaf step and the parts of
+// the shade pass in the assembly; otherwise the markers are nothing
 #ifndef RT_ASM_MARK
 #define RT_ASM_MARK(text)
 #endif
