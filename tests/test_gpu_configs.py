@@ -238,3 +238,82 @@ def read_png_any(path):
                     p = a if (pa <= pb and pa <= pc) else (up[x] if pb <= pc else c)
                 out[y, x] = (row[x] + p) & 255
     return out.reshape(h, w, 3).astype(np.uint8)
+
+
+def _full_size_frame_properties(R, hs, mode_bar_fp32_rays, depth=50):
+    w, h, spp = 3840, 2160, 4
+    sc = hs.upload()
+    n = w * h * 3
+    whole_buf, part_buf = R.DeviceBuffer(n * 8), R.DeviceBuffer(n * 8)
+    st = sc.render(whole_buf.ptr, w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=5)
+    whole = whole_buf.download(np.float64, (h, w, 3))
+    assert np.isfinite(whole).all() and (whole >= 0).all() and whole.mean() > 0.01
+    assert st["rays"] > w * h * spp
+
+    def close(a, b):
+        return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
+
+    a = sc.render(part_buf.ptr, w, h, 0, 2, depth, R.MODE_FAST_FP64, seed=5)
+    b = sc.render(part_buf.ptr, w, h, 2, spp, depth, R.MODE_FAST_FP64, seed=5, flags=R.FLAG_ACCUMULATE)
+    assert a["rays"] + b["rays"] == st["rays"] and a["rejected"] + b["rejected"] == st["rejected"]
+    assert close(part_buf.download(np.float64, (h, w, 3)), whole) <= 1e-12
+
+    part_buf.upload(np.zeros(n, np.float64))
+    a = sc.render(part_buf.ptr, w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=5, y_begin=0, y_end=1000)
+    b = sc.render(part_buf.ptr, w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=5, y_begin=1000, y_end=h)
+    assert a["rays"] + b["rays"] == st["rays"] and a["rejected"] + b["rejected"] == st["rejected"]
+    assert close(part_buf.download(np.float64, (h, w, 3)), whole) <= 1e-12
+
+    again = sc.render(part_buf.ptr, w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=5)
+    assert (again["rays"], again["rejected"]) == (st["rays"], st["rejected"])
+
+    # one sample per pixel of the whole 4K frame is what the oracle does in a second on the box's cores: same streams, same bar as the small frames
+    osc = O.scene_from_arrays(hs.arrays(), 1)
+    want, _, cnt = osc.render(0, 1, depth, O.RNG_COUNTER, seed=5, n_threads=16, want_rgb=False)
+    one = sc.render(part_buf.ptr, w, h, 0, 1, depth, R.MODE_FAST_FP64, seed=5)
+    got = part_buf.download(np.float64, (h, w, 3))
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, float((rel.max(axis=2) > 1e-9).mean())
+    assert abs(one["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]), (one["rays"], int(cnt[0]))
+    osc.free()
+
+    f32_buf = R.DeviceBuffer(n * 4)
+    st32 = sc.render(f32_buf.ptr, w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=5)
+    f32 = f32_buf.download(np.float32, (h, w, 3)).astype(np.float64)
+    assert abs(st32["rays"] - st["rays"]) <= mode_bar_fp32_rays * st["rays"]
+    assert abs(f32.mean() - whole.mean()) <= 0.01 * whole.mean()
+    for buf in (whole_buf, part_buf, f32_buf):
+        buf.free()
+    sc.destroy(); hs.free()
+
+
+def test_full_size_frame_properties_on_the_benchmarked_mesh(R, tmp_path):
+    """configs[2] at the size bench.py times (the generated 1.31 M-triangle OBJ, 3840 x 2160, depth 50), where the oracle cannot follow in
+    test time: size-independent properties of the frame instead.  RT_MODE_FAST_FP64, 4 spp:
+    - samples [0, 2) plus samples [2, 4) accumulated into one buffer, and rows [0, 1000) plus rows [1000, 2160) of all four samples (a
+      seam that cuts through 16-row tiles), each equal the whole frame: per-pixel sums to 1e-12 relative (the order of the additions into a
+      tile is the only freedom), ray and rejected-sample counts exactly;
+    - a second render of the whole frame repeats the counts exactly;
+    - one sample per pixel of the whole frame against the oracle on the same streams (1.3 s of CPU): <= 1e-9 relative on >= 99.5 % of the
+      8.3 M pixels, ray counts within 0.2 %;
+    - the fp32 mode traces the same paths up to fp32 silhouette grazes: ray count within 0.5 %, frame mean within 1 %."""
+    from raytracing_amd.host_scenes import HostScene
+    from raytracing_amd.tools.make_mesh import write_scene
+    path = str(tmp_path / "blob8.obj")
+    assert write_scene(path, 8) > 1_300_000
+    _full_size_frame_properties(R, HostScene.obj(path, 3840, 2160, 1, cam_pos=(0, 1.8, 5.0), cam_lookat=(0, 1.0, 0), fov=40.0), 0.005)
+
+
+def test_full_size_frame_properties_on_the_random_spheres(R):
+    """configs[1] at its size (random_scene() + area light, 3840 x 2160, depth 50): the same properties and the same full-frame comparison
+    with the oracle at one sample per pixel as for the mesh above (the general kernel variant, binary nodes, moving spheres, glass, metal,
+    the checker).  The fp32 mode's ray count is held to 1 % (glass and metal paths are longer and diverge more often under fp32 rounding)."""
+    from raytracing_amd.host_scenes import HostScene
+    _full_size_frame_properties(R, HostScene.random_spheres(3840, 2160, 1), 0.01)
+
+
+def test_full_size_frame_properties_on_the_deep_bounce_scene(R):
+    """configs[4] at its size (the random_scene() geometry with 50 % glass, 40 % mirrors, 10 % lambertian, 3840 x 2160, max_depth 200): the
+    same properties and full-frame oracle comparison at one sample per pixel."""
+    from raytracing_amd.host_scenes import HostScene
+    _full_size_frame_properties(R, HostScene.deep_bounce(3840, 2160, 1), 0.01, depth=200)
