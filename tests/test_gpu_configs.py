@@ -317,3 +317,27 @@ def test_full_size_frame_properties_on_the_deep_bounce_scene(R):
     same properties and full-frame oracle comparison at one sample per pixel."""
     from raytracing_amd.host_scenes import HostScene
     _full_size_frame_properties(R, HostScene.deep_bounce(3840, 2160, 1), 0.01, depth=200)
+
+
+def test_config3_soup_of_a_million_triangles_whole_frame(R, tmp_path):
+    """configs[3] at a tenth of its size and the same density (1 M triangles of edge 0.2 in [-23.2, 23.2]^3: 10 per unit volume, 64 MTL
+    materials with a 256 x 256 PNG map_Kd each), seen as bench.py sees the full soup, 1920 x 1080, depth 50: one sample per pixel of the
+    whole frame against the oracle on the same streams, both fp64 modes -- the wide quantised nodes over a tree of a million leaves
+    whose boxes fill space, image textures at every hit."""
+    from raytracing_amd.host_scenes import HostScene
+    from raytracing_amd.tools.make_mesh import write_soup
+    path = str(tmp_path / "soup1m.obj")
+    n = write_soup(path, n_tri=1_000_000, n_mats=64, tex_size=256, extent=23.2, edge=0.2, seed=12345)
+    assert n >= 1_000_000
+    w, h, depth = 1920, 1080, 50
+    hs = HostScene.obj(path, w, h, 1, cam_pos=(0, 2.3, 35.0), cam_lookat=(0, 0, 0), fov=40.0)
+    osc = O.scene_from_arrays(hs.arrays(), 1)
+    want, _, cnt = osc.render(0, 1, depth, O.RNG_COUNTER, seed=3, n_threads=16, want_rgb=False)
+    assert (want.sum(axis=2) > 0).mean() > 0.01, "the frame is lit (at one sample per pixel most paths end rejected or unlit)"
+    sc = hs.upload()
+    for mode in (R.MODE_FAST_FP64, R.MODE_REFERENCE_FP64):
+        got, _, st = sc.render_to_host(w, h, 0, 1, depth, mode, seed=3)
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+        assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, (mode, float((rel.max(axis=2) > 1e-9).mean()))
+        assert abs(st["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]), (mode, st["rays"], int(cnt[0]))
+    sc.destroy(); osc.free(); hs.free()
