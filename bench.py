@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--mesh-level", type=int, default=8, help="icosphere subdivision of the generated mesh: 8 -> 1.31 M triangles")
     ap.add_argument("--split", choices=["spp", "rows"], default="spp", help="N > 1: split the frame's samples (default) or its rows over the ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the cpu_baseline leg (full resolution): 16 = about 12 s of work on 16 cores for the mesh workload")
     return ap.parse_args()
 
 
@@ -138,7 +138,7 @@ def image_check(args, R, O, s, scene, mode):
 def cpu_reference(args, obj_path):
     """The REAL reference (oracle/_ref/ref_harness: /root/reference's own sources, built in the dev container by `make -C oracle ref`;
     the binary travels with the tree, the sources do not) on one host thread -- its best configuration: its OpenMP loop serialises on
-    rand()'s lock.  Bounded sample: the workload's scene at 1/3 of the resolution, 1 spp.  Returns None when the binary is not there."""
+    rand()'s lock.  Bounded sample: the workload's scene at 1/3 of the resolution, REF_SPP samples per pixel (about 8 s).  Returns None when the binary is not there."""
     import re
     import subprocess
     import tempfile
@@ -146,11 +146,12 @@ def cpu_reference(args, obj_path):
     if not os.path.exists(exe):
         return None
     w, h = max(args.width // 3, 16), max(args.height // 3, 16)
+    ref_spp = 1 if args.workload == "soup" else REF_SPP          # a soup ray costs the CPU tree hundreds of box tests
     with tempfile.TemporaryDirectory() as tmp:
         if args.workload == "random_spheres":
-            cmd = [exe, tmp, "time_c0", "1", str(w), str(h), "1", str(args.depth)]
+            cmd = [exe, tmp, "time_c0", "1", str(w), str(h), str(ref_spp), str(args.depth)]
         else:
-            cmd = [exe, tmp, "time_obj", obj_path, str(w), str(h), "1", str(args.depth)] + [str(v) for v in OBJ_CAMERA[args.workload]]
+            cmd = [exe, tmp, "time_obj", obj_path, str(w), str(h), str(ref_spp), str(args.depth)] + [str(v) for v in OBJ_CAMERA[args.workload]]
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
         except (OSError, subprocess.TimeoutExpired):
@@ -161,14 +162,17 @@ def cpu_reference(args, obj_path):
         return None
     n, dt = int(rays.group(1)), float(secs.group(1))
     return {"value": round(n / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "reference",
-            "sample": f"{args.workload} {w}x{h}, 1 spp, max_depth {args.depth}: {n} rays in {dt:.2f} s (the reference's own trace() loop, single thread, rand())"}
+            "sample": f"{args.workload} {w}x{h}, {ref_spp} spp, max_depth {args.depth}: {n} rays in {dt:.2f} s (the reference's own trace() loop, single thread, rand())"}
 
 
+REF_SPP = 8        # samples per pixel of the cpu_reference leg
 OBJ_CAMERA = {"obj": (0, 1.8, 5.0, 0, 1.0, 0, 40.0), "soup": (0, 5.0, 75.0, 0, 0, 0, 40.0)}     # position, look-at, fov of the OBJ workloads
 
 
 def main():
     args = parse()
+    if args.workload == "soup":
+        args.cpu_spp = 1                  # bounded sample: a soup ray costs the CPU tree hundreds of box tests
     import torch
     import torch.distributed as dist
     import raytracing_amd as R
