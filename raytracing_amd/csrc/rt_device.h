@@ -405,10 +405,19 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
     }
 }
 
+// Scene classes the fast kernels are compiled for (kFull): 0 spheres, rects and triangles; 1 also boxes / volumes; 2 also instances;
+// 3 an OBJ-loader scene (triangles only, every material a phong, no checker; 4: unused); 5 the "ray tracing in one weekend" class --
+// spheres, moving spheres and rects, lambertian / metal / dielectric / emissive, constant and checker textures, rect lights: no
+// triangle, phong, fog or image-texture code.  Every kind a variant cannot meet costs it registers whether the scene holds one or not.
+constexpr bool class_is_obj(int kFull) { return kFull == 3 || kFull == 4; }
+constexpr int class_mat(int kFull) { return class_is_obj(kFull) ? 1 : (kFull == 5 ? 2 : 0); }       // kMat of the mat_* functions
+constexpr int class_tex(int kFull) { return kFull == 5 ? 2 : 0; }                                   // kTex of tex_color
+constexpr int class_light(int kFull) { return kFull == 5 ? 1 : 0; }                                 // kLight of the light functions
+
 template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R a, b;
-    if constexpr (kFull >= 3) {                                          // a scene of triangles only (what the OBJ loader builds)
+    if constexpr (class_is_obj(kFull)) {                                 // a scene of triangles only (what the OBJ loader builds)
         if (sizeof(R) == sizeof(float) && p.id == r.from) return false;
         return tri_t(p, r, t_min, t_max, t, a, b);
     }
@@ -425,7 +434,7 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
         const bool moving = p.kind() == RT_PRIM_MSPHERE;
         return sphere_t(moving ? msphere_center(p, r.time) : vec3<R>(p.g[0], p.g[1], p.g[2]), moving ? p.g[8] : p.g[3], r, t_min, t_max, t);
     }
-    case RT_PRIM_TRIANGLE: return tri_t(p, r, t_min, t_max, t, a, b);
+    case RT_PRIM_TRIANGLE: if constexpr (kFull != 5) return tri_t(p, r, t_min, t_max, t, a, b); else return false;
     case RT_PRIM_BOX: if constexpr (kFull == 1 || kFull == 2) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
     case RT_PRIM_VOLUME: if constexpr (kFull == 1 || kFull == 2) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
@@ -472,7 +481,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
     h.mat = p.mat;
     h.id = p.id;
     h.u = h.v = R(0);
-    switch (kFull >= 3 ? RT_PRIM_TRIANGLE : p.kind()) {
+    switch (class_is_obj(kFull) ? RT_PRIM_TRIANGLE : p.kind()) {
     case RT_PRIM_SPHERE:
     case RT_PRIM_MSPHERE: {
         vec3<R> c = p.kind() == RT_PRIM_SPHERE ? vec3<R>(p.g[0], p.g[1], p.g[2]) : msphere_center(p, r.time);
@@ -480,7 +489,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         h.pos = r.o + t * r.d;
         vec3<R> n = (h.pos - c) / radius;
         set_face_normal(h, r, n);
-        if (need_uv) {                                                      // primitive.hpp:67-74
+        if (kFull != 5 && need_uv) {                                        // primitive.hpp:67-74 (only an image texture reads uv)
             R theta = rt_acos(-n.y);
             R phi = rt_atan2(-n.z, n.x) + consts<R>::pi;
             h.u = phi / (R(2) * consts<R>::pi);
@@ -488,7 +497,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         }
         break;
     }
-    case RT_PRIM_TRIANGLE: {
+    case RT_PRIM_TRIANGLE: if constexpr (kFull != 5) {
         R tt, u, v;
         tri_t(p, r, -rt_inf<R>(), rt_inf<R>(), tt, u, v);                   // same arithmetic as the accepted test
         h.pos = r.o + t * r.d;
@@ -500,7 +509,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         vec3<R> n = (u * n1 + v * n2) + w * n0;                             // polygon.hpp:179-182 (not re-normalised)
         set_face_normal(h, r, n);
         break;
-    }
+    } else break;
     case RT_PRIM_BOX: {
         if constexpr (kFull == 1 || kFull == 2) {
             R tt;
@@ -763,7 +772,8 @@ template <> __device__ inline float checker_sine<float>(const vec3<float>& pos)
     auto s = [](float rev) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev)); };
     return s(k * pos.x) * s(k * pos.y) * s(k * pos.z);
 }
-template <typename R> __device__ inline vec3<R> tex_color(const Scene<R>& sc, int ti, const vec3<R>& pos, R u, R v)
+// kTex = 2: the scene holds no image texture
+template <typename R, int kTex = 0> __device__ inline vec3<R> tex_color(const Scene<R>& sc, int ti, const vec3<R>& pos, R u, R v)
 {
     for (int level = 0; level < 8; level++) {
         const Tex<R>& t = sc.texs[ti];
@@ -773,7 +783,7 @@ template <typename R> __device__ inline vec3<R> tex_color(const Scene<R>& sc, in
             ti = sine < R(0) ? t.a : t.b;
             continue;
         }
-        if (t.kind == RT_TEX_IMAGE) {                                                       // texture.hpp:95-124
+        if (kTex != 2 && t.kind == RT_TEX_IMAGE) {                                          // texture.hpp:95-124
             if (t.a <= 0) return vec3<R>(R(0), R(1), R(1));
             R uu = u < R(0) ? R(0) : (u > R(1) ? R(1) : u);
             R vv = R(1) - (v < R(0) ? R(0) : (v > R(1) ? R(1) : v));
@@ -832,11 +842,11 @@ template <typename R> __device__ inline vec3<R> cosine_sample(Rng& g, const vec3
 
 // `texc`: the material's texture evaluated at the hit (tex_color draws no random numbers, so it is evaluated once, before the
 // per-material branches, for every lane whose material has one: one copy of the texture code, executed by all of them together)
-// kMat = 1: the caller knows every material of the scene is a phong (what the OBJ loader builds, loader.hpp:160)
+// kMat = 1: the caller knows every material of the scene is a phong (what the OBJ loader builds, loader.hpp:160); 2: none is a phong or a fog
 template <typename R, int kMat = 0> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const Hit<R>& h, const vec3<R>& texc)
 {
     if (kMat != 1 && m.kind == RT_MAT_EMISSIVE) return h.front ? texc : vec3<R>();                                                   // material.hpp:146-154
-    if (kMat == 1 || m.kind == RT_MAT_PHONG) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
+    if (kMat == 1 || (kMat != 2 && m.kind == RT_MAT_PHONG)) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
     return vec3<R>();
 }
 
@@ -874,11 +884,12 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         dir = glass_dir(g, wi, h, m.d[0]);
         return true;
     case RT_MAT_FOG:                                                                        // material.hpp:174-180; pdf() stays the base class's 0 (:14)
+        if constexpr (kMat == 2) return false;
         spec = false;
         dir = random_sphere<R>(g);
         att = texc;
         return true;
-    case RT_MAT_PHONG: {                                                                    // material.hpp:211-255
+    case RT_MAT_PHONG: if constexpr (kMat == 2) return false; else {                         // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
         vec3<R> base = (m.tex >= 0) ? texc : vec3<R>(m.d[1], m.d[2], m.d[3]);
         if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
@@ -969,7 +980,7 @@ template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Ma
         R c = dot(h.normal, normalize(wo.d));
         return c > consts<R>::eps ? R(1) : R(0);
     }
-    case RT_MAT_PHONG: {                                                                    // material.hpp:257-266
+    case RT_MAT_PHONG: if constexpr (kMat == 2) return R(0); else {                          // material.hpp:257-266
         R c = dot(h.normal, normalize(wo.d));
         if (!fixed && nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);   // fixed: the diffuse lobe's pdf, no second roll
         return c > R(0) ? c / consts<R>::pi : R(0);
@@ -979,7 +990,8 @@ template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Ma
 }
 
 // ------------------------------------------------------------------ lights (group.hpp:104-119 over planexz / triangle)
-template <typename R> __device__ inline R light_pdf(const Scene<R>& sc, int li, const vec3<R>& origin, const vec3<R>& value)
+// kLight = 1: every light of the scene is a rect (no triangle lights)
+template <typename R, int kLight = 0> __device__ inline R light_pdf(const Scene<R>& sc, int li, const vec3<R>& origin, const vec3<R>& value)
 {
     const Prim<R>& p = sc.lights[li];
     Ray<R> r; r.o = origin; r.d = value; r.time = R(0);                                     // ray(origin, value): time 0, t_min 1e-3, t_max inf
@@ -992,7 +1004,7 @@ template <typename R> __device__ inline R light_pdf(const Scene<R>& sc, int li, 
         normal = dot(r.d, n) < R(0) ? n : -n;
         area = (p.g[1] - p.g[0]) * (p.g[3] - p.g[2]);
     }
-    else if (p.kind() == RT_PRIM_TRIANGLE) {                                                  // polygon.hpp:140-151
+    else if (kLight != 1 && p.kind() == RT_PRIM_TRIANGLE) {                                   // polygon.hpp:140-151
         R u, v;
         if (!tri_t(p, r, consts<R>::tmin, rt_inf<R>(), t, u, v)) return R(0);
         const TriShade<R>& s = sc.light_tris[li];
@@ -1010,7 +1022,7 @@ template <typename R> __device__ inline R light_pdf(const Scene<R>& sc, int li, 
     return dist2 / (cosine * area);
 }
 
-template <typename R> __device__ inline vec3<R> light_rand(const Scene<R>& sc, Rng& g, const vec3<R>& origin)
+template <typename R, int kLight = 0> __device__ inline vec3<R> light_rand(const Scene<R>& sc, Rng& g, const vec3<R>& origin)
 {
     int idx = (int) uniform<R>(g, R(0), R(sc.n_lights));                                    // group.hpp:117, util.hpp:42-45
     if (idx >= sc.n_lights) idx = sc.n_lights - 1;                                          // fp32 only: guards u*n rounding up to n
@@ -1020,7 +1032,7 @@ template <typename R> __device__ inline vec3<R> light_rand(const Scene<R>& sc, R
         R x = uniform<R>(g, p.g[0], p.g[1]);
         return vec3<R>(x, p.g[4], z) - origin;
     }
-    if (p.kind() == RT_PRIM_TRIANGLE) {                                                       // polygon.hpp:153-167
+    if (kLight != 1 && p.kind() == RT_PRIM_TRIANGLE) {                                        // polygon.hpp:153-167
         vec3<R> p0(p.g[0], p.g[1], p.g[2]), e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
         R u = uniform<R>(g), v = uniform<R>(g);
         vec3<R> q = (u + v > R(1)) ? (p0 + (R(1) - u) * e1) + (R(1) - v) * e2 : (p0 + u * e1) + v * e2;
@@ -1029,11 +1041,11 @@ template <typename R> __device__ inline vec3<R> light_rand(const Scene<R>& sc, R
     return vec3<R>(R(1), R(0), R(0));                                                       // object.hpp:17
 }
 
-template <typename R> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value)
+template <typename R, int kLight = 0> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value)
 {
     R weight = R(1) / R(sc.n_lights);
     R avg = R(0);
-    for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf(sc, i, origin, value);
+    for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf<R, kLight>(sc, i, origin, value);
     return avg;
 }
 

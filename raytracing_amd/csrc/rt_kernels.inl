@@ -80,9 +80,10 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             }
             return launch_queue<RT_REAL, false, 0>(count, grid, qlds, s, sc, a, accum, counters, q_pools, q_locks);
         }
-        // variants by scene content (rt_device.h prim_t): 2 instances (unquantised nodes), 1 boxes or volumes, 3 an OBJ-loader scene, 0 the rest
+        // variants by scene content (rt_device.h class_*): 2 instances (unquantised nodes), 1 boxes or volumes, 3 an OBJ-loader scene, 5 spheres and rects, 0 the rest
         if (a.kinds == 2) return launch_wave<RT_REAL, false, 2>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 1) return launch_wave<RT_REAL, false, 1>(count, grid, lds, s, sc, a, accum, counters);
+        if (a.kinds == 5) return launch_wave<RT_REAL, false, 5>(count, grid, lds, s, sc, a, accum, counters);          // spheres and rects (rt_device.h class_*)
         if (a.kinds == 3) {
             if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
             return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);

@@ -66,7 +66,7 @@ __device__ inline void q_store_hit(QSlot<float>* s, float t, int32_t hit)
 __device__ inline void q_store_hit(QSlot<double>* s, double t, int32_t hit) { s->t = t; s->hit = hit; }
 
 template <typename R, bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32))
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32))
 render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters, QSlot<R>* __restrict__ pools,
                     unsigned int* __restrict__ pool_locks)
 {
@@ -155,7 +155,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         q_load_ray(pool + slot, ray);
                         trav_begin(tv, best, ray, stack_base);
-                        if (kFull >= 3 && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;   // see rt_wave.h
+                        if (class_is_obj(kFull) && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;   // see rt_wave.h
                     }
                 }
                 n_rays -= k;
@@ -200,16 +200,16 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                             fill_record<R, kFull>(fprims[S.hit], sc.side(), pr, S.t, sc.need_uv != 0, h);
                             const Mat<R>& mt = sc.mats[h.mat];
                             const vec3<R> texc = mt.tex >= 0 ? tex_color(sc, mt.tex, h.pos, h.u, h.v) : vec3<R>();
-                            vec3<R> emission = mat_emit<R, (kFull >= 3)>(mt, h, texc);
+                            vec3<R> emission = mat_emit<R, class_mat(kFull)>(mt, h, texc);
                             Ray<R> wo; wo.time = R(0);
                             vec3<R> att;
                             bool spec = false;
-                            if (mat_shading<R, (kFull >= 3)>(g, mt, pr, h, texc, wo, att, spec)) {
+                            if (mat_shading<R, class_mat(kFull)>(g, mt, pr, h, texc, wo, att, spec)) {
                                 R pdf, mpdf;
-                                if (spec) { mpdf = mat_pdf<R, (kFull >= 3)>(g, mt, h, wo); pdf = mpdf; }
+                                if (spec) { mpdf = mat_pdf<R, class_mat(kFull)>(g, mt, h, wo); pdf = mpdf; }
                                 else {
                                     if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = pr.time; }
-                                    mpdf = mat_pdf<R, (kFull >= 3)>(g, mt, h, wo);
+                                    mpdf = mat_pdf<R, class_mat(kFull)>(g, mt, h, wo);
                                     pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
                                 }
                                 R inv = R(1) / pdf;

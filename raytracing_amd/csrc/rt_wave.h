@@ -35,6 +35,15 @@
 #ifndef RT_WAVES_FP64
 #define RT_WAVES_FP64 3
 #endif
+// the spheres-and-rects variants (rt_device.h class_*: no triangle, phong, fog or image-texture code) are lean enough for more waves.
+// 4K, random spheres 32 spp / deep bounce 16 spp, ms: fp64 85.0 / 91.2 at 3 waves, 81.1 / 84.4 at 4, 129 / 128 at 5 (spills);
+// fp32 52.7 / 59.6 at 4, 48.9 / 57.9 at 5, the same at 6
+#ifndef RT_WAVES_FP64_SPHERES
+#define RT_WAVES_FP64_SPHERES 4
+#endif
+#ifndef RT_WAVES_SPHERES
+#define RT_WAVES_SPHERES 5
+#endif
 
 // tools/node_step_isa.sh compiles with -DRT_ASM_MARK(text)=asm volatile(text) to find the node visit, the leaf step and the parts of
 // the shade pass in the assembly; otherwise the markers are nothing
@@ -180,7 +189,7 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
 }
 
 template <typename R, bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
                                                                          unsigned long long* __restrict__ counters)
 {
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut
@@ -329,26 +338,26 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                 RT_ASM_MARK("; shade: record");
                 fill_record<R, kFull>(fprims[tv.hit], sc.side(), ray, closest_of(tv, best), sc.need_uv != 0, h);
                 const Mat<R>& m = sc.mats[h.mat];
-                const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
-                vec3<R> emission = mat_emit<R, (kFull >= 3)>(m, h, texc);
+                const vec3<R> texc = m.tex >= 0 ? tex_color<R, class_tex(kFull)>(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
+                vec3<R> emission = mat_emit<R, class_mat(kFull)>(m, h, texc);
                 Ray<R> wo; wo.time = R(0);                                                  // `ray wo;` raytracing.cpp:41
                 vec3<R> att;
                 bool spec = false;
                 const bool fixed = (a.flags & RT_FLAG_COMPAT_FIXED) != 0;
                 RT_ASM_MARK("; shade: scatter");
-                if (mat_shading<R, (kFull >= 3)>(g, m, ray, h, texc, wo, att, spec, fixed)) {
+                if (mat_shading<R, class_mat(kFull)>(g, m, ray, h, texc, wo, att, spec, fixed)) {
                     R pdf, mpdf;
                     bool dropped = false;
                     RT_ASM_MARK("; shade: pdf");
                     if (!(fixed && spec)) {
                         if (spec) {                                                         // raytracing.cpp:51-54
-                            mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo);
+                            mpdf = mat_pdf<R, class_mat(kFull)>(g, m, h, wo);
                             pdf = mpdf;
                         }
                         else {                                                              // raytracing.cpp:55-61
-                            if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
-                            mpdf = mat_pdf<R, (kFull >= 3)>(g, m, h, wo, fixed);
-                            pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf);
+                            if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand<R, class_light(kFull)>(sc, g, h.pos); wo.time = ray.time; }
+                            mpdf = mat_pdf<R, class_mat(kFull)>(g, m, h, wo, fixed);
+                            pdf = R(0.5) * (lights_pdf<R, class_light(kFull)>(sc, h.pos, wo.d) + mpdf);
                         }
                         // RT_FLAG_COMPAT_FIXED: a direction of zero probability contributes nothing (the reference forms 0 * inf)
                         if (fixed && (!(pdf > R(0)) || !(mpdf > R(0)))) dropped = true;
@@ -357,6 +366,12 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                         att = inv * w;
                     }                                                                       // RT_FLAG_COMPAT_FIXED: a delta lobe weighs its attenuation
                     RT_ASM_MARK("; shade: tail");
+                    // `dropped` goes through a register here on purpose.  Left as a lane mask, hipcc 7.2 -O2/-O3 compiled the float
+                    // spheres-and-rects variant so that paths whose earlier bounce was specular were not dropped at a later diffuse
+                    // bounce (RT_FLAG_COMPAT_FIXED: +32 % rays on the fixture scene, fireflies on the metal sphere); -O1, the other
+                    // variants and R = double were right.  Found by the per-pixel ray counts against the fp64 mode, which
+                    // test_fast_ray_counts_match_fp64_per_pixel now also holds under RT_FLAG_COMPAT_FIXED.
+                    { int dropped_reg = dropped; asm volatile("" : "+v"(dropped_reg)); dropped = dropped_reg != 0; }
                     if (!dropped) {
                     beta = beta * att;
                     // a non-finite 1/pdf or weight (also 0 * inf) poisons the sample whatever follows: the recursion multiplies it in
@@ -371,7 +386,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     // here: counted as the ray it is, black, the path ends (rejected: its pdf is 0).  Before, the slab test's nudge of zero
                     // components made it a diagonal ray that walked the whole tree: mesh workload 152 -> 69 ms per 64 spp.
                     // (Spheres answer such a ray with NaN roots: the other variants walk on.)
-                    if (kFull >= 3 && !done && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) { zero_ray = true; done = true; path_rays++; }
+                    if (class_is_obj(kFull) && !done && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) { zero_ray = true; done = true; path_rays++; }
                     }
                 }
                 else L = beta * emission;                                                   // the path ends on an emitter (or absorber)

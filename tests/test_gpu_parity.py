@@ -344,6 +344,15 @@ def test_fast_ray_counts_match_fp64_per_pixel(R, which, limit):
         frac = float((cnt[..., 0].astype(np.float64) != ref[..., 0]).mean())
         assert frac <= limit, (name, frac)
         assert abs(st["rays"] - st64["rays"]) <= 5e-4 * st64["rays"], (name, st["rays"], st64["rays"])
+    # the same under RT_FLAG_COMPAT_FIXED (the kernels that take the flag): paths end where a sample is dropped or absorbed, so a flag
+    # that is lost on the way shows as extra segments -- how the `dropped` lane-mask miscompile noted in rt_wave.h was found
+    fixed = R.FLAG_COMPAT_FIXED | R.FLAG_DEBUG_RAY_COUNTS
+    ref, _, st64 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_REFERENCE_FP64, seed=3, flags=fixed)
+    for name, mode in (("fast fixed", R.MODE_FAST_FP32), ("reftree fixed", R.MODE_FP32_REFERENCE_TREE), ("fast fp64 fixed", R.MODE_FAST_FP64)):
+        cnt, _, st = sc.render_to_host(w, h, 0, spp, depth, mode, seed=3, flags=fixed)
+        frac = float((cnt[..., 0].astype(np.float64) != ref[..., 0]).mean())
+        assert frac <= (1e-4 if mode == R.MODE_FAST_FP64 else 2 * limit), (name, frac)
+        assert abs(st["rays"] - st64["rays"]) <= 1e-3 * st64["rays"], (name, st["rays"], st64["rays"])
     sc.destroy()
     hs.free()
 
