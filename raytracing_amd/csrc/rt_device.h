@@ -406,13 +406,16 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
 }
 
 // Scene classes the fast kernels are compiled for (kFull): 0 spheres, rects and triangles; 1 also boxes / volumes; 2 also instances;
-// 3 an OBJ-loader scene (triangles only, every material a phong, no checker; 4: unused); 5 the "ray tracing in one weekend" class --
-// spheres, moving spheres and rects, lambertian / metal / dielectric / emissive, constant and checker textures, rect lights: no
-// triangle, phong, fog or image-texture code.  Every kind a variant cannot meet costs it registers whether the scene holds one or not.
+// 3 an OBJ-loader scene (triangles only, every material a phong, no checker; 4: unused); 5, 6, 7: the classes 0, 1, 2 of scenes in the
+// style of "ray tracing in one weekend / the next week" -- no triangle, no phong, no image texture, rect lights only (5 also without
+// fog, which only a volume carries).  Every kind a variant could meet costs it registers whether the scene holds one or not.
 constexpr bool class_is_obj(int kFull) { return kFull == 3 || kFull == 4; }
-constexpr int class_mat(int kFull) { return class_is_obj(kFull) ? 1 : (kFull == 5 ? 2 : 0); }       // kMat of the mat_* functions
-constexpr int class_tex(int kFull) { return kFull == 5 ? 2 : 0; }                                   // kTex of tex_color
-constexpr int class_light(int kFull) { return kFull == 5 ? 1 : 0; }                                 // kLight of the light functions
+constexpr bool class_no_tri(int kFull) { return kFull == 5 || kFull == 6 || kFull == 7; }
+constexpr bool class_boxes(int kFull) { return kFull == 1 || kFull == 2 || kFull == 6 || kFull == 7; }      // boxes and volumes
+constexpr bool class_instances(int kFull) { return kFull == 2 || kFull == 7; }
+constexpr int class_mat(int kFull) { return class_is_obj(kFull) ? 1 : (kFull == 5 ? 2 : (class_no_tri(kFull) ? 3 : 0)); }   // kMat of the mat_* functions
+constexpr int class_tex(int kFull) { return class_no_tri(kFull) ? 2 : 0; }                                                 // kTex of tex_color
+constexpr int class_light(int kFull) { return class_no_tri(kFull) ? 1 : 0; }                                               // kLight of the light functions
 
 template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
@@ -434,25 +437,23 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
         const bool moving = p.kind() == RT_PRIM_MSPHERE;
         return sphere_t(moving ? msphere_center(p, r.time) : vec3<R>(p.g[0], p.g[1], p.g[2]), moving ? p.g[8] : p.g[3], r, t_min, t_max, t);
     }
-    case RT_PRIM_TRIANGLE: if constexpr (kFull != 5) return tri_t(p, r, t_min, t_max, t, a, b); else return false;
-    case RT_PRIM_BOX: if constexpr (kFull == 1 || kFull == 2) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
-    case RT_PRIM_VOLUME: if constexpr (kFull == 1 || kFull == 2) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
+    case RT_PRIM_TRIANGLE: if constexpr (!class_no_tri(kFull)) return tri_t(p, r, t_min, t_max, t, a, b); else return false;
+    case RT_PRIM_BOX: if constexpr (class_boxes(kFull)) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
+    case RT_PRIM_VOLUME: if constexpr (class_boxes(kFull)) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)
-// kFull: what the caller knows about the scene -- 0: spheres, rects and triangles only; 1: also boxes / volumes; 2: also instances;
-// 3: an OBJ-loader scene -- triangles only, every material a phong (4: the same, compiled for the occupancy of the other variants).
-// The fast kernel is compiled for each: carrying the box, volume and instance code costs the sphere / triangle workloads 5-10 %,
-// the instance check costs the Cornell box 15 %.
+// kFull: the scene class (class_* above).  Carrying the box, volume and instance code costs the sphere / triangle workloads 5-10 %, the
+// instance check costs the Cornell box 15 %; the triangle / phong / image-texture code costs the sphere scenes 7-18 %.
 template <typename R, int kFull = 2> __device__ inline bool prim_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g = nullptr)
 {
-    const int xi = kFull == 2 ? p.xform() : -1;
-    if (kFull == 2 && xi >= 0) {
+    const int xi = class_instances(kFull) ? p.xform() : -1;
+    if (class_instances(kFull) && xi >= 0) {
         Ray<R> tr, rr;
         xform_rays(aux.xforms[xi], r, tr, rr);
-        return prim_t_local<R, 2>(p, aux, rr, t_min, t_max, t, g);
+        return prim_t_local<R, kFull>(p, aux, rr, t_min, t_max, t, g);
     }
     return prim_t_local<R, kFull>(p, aux, r, t_min, t_max, t, g);
 }
@@ -489,7 +490,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         h.pos = r.o + t * r.d;
         vec3<R> n = (h.pos - c) / radius;
         set_face_normal(h, r, n);
-        if (kFull != 5 && need_uv) {                                        // primitive.hpp:67-74 (only an image texture reads uv)
+        if (!class_no_tri(kFull) && need_uv) {                              // primitive.hpp:67-74 (only an image texture reads uv)
             R theta = rt_acos(-n.y);
             R phi = rt_atan2(-n.z, n.x) + consts<R>::pi;
             h.u = phi / (R(2) * consts<R>::pi);
@@ -497,7 +498,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         }
         break;
     }
-    case RT_PRIM_TRIANGLE: if constexpr (kFull != 5) {
+    case RT_PRIM_TRIANGLE: if constexpr (!class_no_tri(kFull)) {
         R tt, u, v;
         tri_t(p, r, -rt_inf<R>(), rt_inf<R>(), tt, u, v);                   // same arithmetic as the accepted test
         h.pos = r.o + t * r.d;
@@ -511,7 +512,7 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
         break;
     } else break;
     case RT_PRIM_BOX: {
-        if constexpr (kFull == 1 || kFull == 2) {
+        if constexpr (class_boxes(kFull)) {
             R tt;
             box_t<R>(p, tris[p.id], r, consts<R>::tmin, rt_inf<R>(), tt, &h);   // the closest side again: same arithmetic as the accepted test
         }
@@ -541,13 +542,13 @@ template <typename R, int kFull = 2> __device__ inline void fill_record_local(co
 
 template <typename R, int kFull = 2> __device__ inline void fill_record(const Prim<R>& p, Side<R> tris, const Ray<R>& r, R t, bool need_uv, Hit<R>& h)
 {
-    const int xi = kFull == 2 ? p.xform() : -1;
-    if (kFull != 2 || xi < 0) { fill_record_local<R, kFull>(p, tris, r, t, need_uv, h); return; }
+    const int xi = class_instances(kFull) ? p.xform() : -1;
+    if (!class_instances(kFull) || xi < 0) { fill_record_local<R, kFull>(p, tris, r, t, need_uv, h); return; }
     // member of an instance: the record is made in the instance's frame and comes back out through both wrappers' set_face_normal
     const Xform<R>& x = tris.xforms[xi];
     Ray<R> tr, rr;
     xform_rays(x, r, tr, rr);
-    fill_record_local<R, 2>(p, tris, rr, t, need_uv, h);
+    fill_record_local<R, kFull>(p, tris, rr, t, need_uv, h);
     if (x.flags & RT_PRIM_FLAG_ROTATEY) {                                   // transform.hpp:99-110
         vec3<R> position = h.pos, normal = h.normal;
         position.x = x.cs * h.pos.x + x.sn * h.pos.z;
@@ -842,11 +843,11 @@ template <typename R> __device__ inline vec3<R> cosine_sample(Rng& g, const vec3
 
 // `texc`: the material's texture evaluated at the hit (tex_color draws no random numbers, so it is evaluated once, before the
 // per-material branches, for every lane whose material has one: one copy of the texture code, executed by all of them together)
-// kMat = 1: the caller knows every material of the scene is a phong (what the OBJ loader builds, loader.hpp:160); 2: none is a phong or a fog
+// kMat = 1: the caller knows every material of the scene is a phong (what the OBJ loader builds, loader.hpp:160); 2: none is a phong or a fog; 3: none is a phong
 template <typename R, int kMat = 0> __device__ inline vec3<R> mat_emit(const Mat<R>& m, const Hit<R>& h, const vec3<R>& texc)
 {
     if (kMat != 1 && m.kind == RT_MAT_EMISSIVE) return h.front ? texc : vec3<R>();                                                   // material.hpp:146-154
-    if (kMat == 1 || (kMat != 2 && m.kind == RT_MAT_PHONG)) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
+    if (kMat == 1 || (kMat != 2 && kMat != 3 && m.kind == RT_MAT_PHONG)) return (nz3(m.d + 7) && h.front) ? vec3<R>(m.d[7], m.d[8], m.d[9]) : vec3<R>();        // material.hpp:201-209
     return vec3<R>();
 }
 
@@ -889,7 +890,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         dir = random_sphere<R>(g);
         att = texc;
         return true;
-    case RT_MAT_PHONG: if constexpr (kMat == 2) return false; else {                         // material.hpp:211-255
+    case RT_MAT_PHONG: if constexpr (kMat == 2 || kMat == 3) return false; else {            // material.hpp:211-255
         if (nz3(m.d + 7)) return false;
         vec3<R> base = (m.tex >= 0) ? texc : vec3<R>(m.d[1], m.d[2], m.d[3]);
         if (nz3(m.d + 4) && uniform<R>(g) < R(0.5)) {
@@ -980,7 +981,7 @@ template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Ma
         R c = dot(h.normal, normalize(wo.d));
         return c > consts<R>::eps ? R(1) : R(0);
     }
-    case RT_MAT_PHONG: if constexpr (kMat == 2) return R(0); else {                          // material.hpp:257-266
+    case RT_MAT_PHONG: if constexpr (kMat == 2 || kMat == 3) return R(0); else {             // material.hpp:257-266
         R c = dot(h.normal, normalize(wo.d));
         if (!fixed && nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);   // fixed: the diffuse lobe's pdf, no second roll
         return c > R(0) ? c / consts<R>::pi : R(0);

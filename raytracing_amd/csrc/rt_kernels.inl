@@ -84,6 +84,8 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
         if (a.kinds == 2) return launch_wave<RT_REAL, false, 2>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 1) return launch_wave<RT_REAL, false, 1>(count, grid, lds, s, sc, a, accum, counters);
         if (a.kinds == 5) return launch_wave<RT_REAL, false, 5>(count, grid, lds, s, sc, a, accum, counters);          // spheres and rects (rt_device.h class_*)
+        if (a.kinds == 6) return launch_wave<RT_REAL, false, 6>(count, grid, lds, s, sc, a, accum, counters);          // ... with boxes or volumes
+        if (a.kinds == 7) return launch_wave<RT_REAL, false, 7>(count, grid, lds, s, sc, a, accum, counters);          // ... with instances
         if (a.kinds == 3) {
             if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
             return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);

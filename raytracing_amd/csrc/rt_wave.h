@@ -37,7 +37,8 @@
 #endif
 // the spheres-and-rects variants (rt_device.h class_*: no triangle, phong, fog or image-texture code) are lean enough for more waves.
 // 4K, random spheres 32 spp / deep bounce 16 spp, ms: fp64 85.0 / 91.2 at 3 waves, 81.1 / 84.4 at 4, 129 / 128 at 5 (spills);
-// fp32 52.7 / 59.6 at 4, 48.9 / 57.9 at 5, the same at 6
+// fp32 52.7 / 59.6 at 4, 48.9 / 57.9 at 5, the same at 6.  Their twins with boxes / volumes (6) and instances (7) keep the general
+// variants' occupancy: Cornell box 29.8 (fp64) / 15.1 ms (fp32) there against 29.9 / 16.0 at the spheres variants' occupancy.
 #ifndef RT_WAVES_FP64_SPHERES
 #define RT_WAVES_FP64_SPHERES 4
 #endif

@@ -105,7 +105,7 @@ struct rt_scene {
     int32_t n_lights = 0, n_prims = 0, n_ops = 0;
     bool has_volume = false;                  // RT_PRIM_VOLUME present: needs the path's random stream during traversal
     bool has_box = false;                     // RT_PRIM_BOX present
-    bool only_spheres = true;                 // spheres, moving spheres and rects; lambertian / metal / dielectric / emissive; constant and checker textures; rect lights
+    bool only_spheres = true;                 // no triangle, no phong, no image texture, rect lights only (fog only with volumes): the lean variants 5 / 6 / 7
     bool only_triangles = true;               // every primitive is an RT_PRIM_TRIANGLE and every material an RT_MAT_PHONG (an OBJ-loader scene)
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -573,10 +573,9 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     for (int i = 0; i < desc->n_prims; i++) { s->has_volume |= desc->prim_kind[i] == RT_PRIM_VOLUME; s->has_box |= desc->prim_kind[i] == RT_PRIM_BOX; s->only_triangles &= desc->prim_kind[i] == RT_PRIM_TRIANGLE; }
     for (int i = 0; i < desc->n_mats; i++) s->only_triangles &= desc->mat_kind[i] == RT_MAT_PHONG;
     auto is_rect = [](int k) { return k == RT_PRIM_PLANEXY || k == RT_PRIM_PLANEYZ || k == RT_PRIM_PLANEXZ; };
-    for (int i = 0; i < desc->n_prims; i++) s->only_spheres &= desc->prim_kind[i] == RT_PRIM_SPHERE || desc->prim_kind[i] == RT_PRIM_MSPHERE || is_rect(desc->prim_kind[i]);
+    for (int i = 0; i < desc->n_prims; i++) s->only_spheres &= desc->prim_kind[i] != RT_PRIM_TRIANGLE;
     for (int i = 0; i < desc->n_lights; i++) s->only_spheres &= is_rect(desc->light_kind[i]);
-    for (int i = 0; i < desc->n_mats; i++)
-        s->only_spheres &= desc->mat_kind[i] == RT_MAT_LAMBERTIAN || desc->mat_kind[i] == RT_MAT_METAL || desc->mat_kind[i] == RT_MAT_DIELECTRIC || desc->mat_kind[i] == RT_MAT_EMISSIVE;
+    for (int i = 0; i < desc->n_mats; i++) s->only_spheres &= desc->mat_kind[i] != RT_MAT_PHONG && (desc->mat_kind[i] != RT_MAT_FOG || s->has_volume);
     for (int i = 0; i < desc->n_tex; i++) s->only_spheres &= desc->tex_kind[i] == RT_TEX_CONSTANT || desc->tex_kind[i] == RT_TEX_CHECKER;
     if (const char* env = std::getenv("RT_LEAN_SPHERES")) s->only_spheres &= std::atoi(env) != 0;      // 0: the general variant (A/B)
     if (hipMalloc((void**) &s->counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
@@ -642,7 +641,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
-    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.xcd_tiles = s->xcd_tiles; a.kinds = s->d32.view.xforms != nullptr ? 2 : ((s->has_box || s->has_volume) ? 1 : (s->only_triangles ? 3 : (s->only_spheres && !s->quantised ? 5 : 0)));
+    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.xcd_tiles = s->xcd_tiles; a.kinds = s->d32.view.xforms != nullptr ? (s->only_spheres ? 7 : 2) : ((s->has_box || s->has_volume) ? (s->only_spheres ? 6 : 1) : (s->only_triangles ? 3 : (s->only_spheres && !s->quantised ? 5 : 0)));
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
         if (s->has_volume) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT: the extend kernel has no random stream, which a volume's intersection test draws from");
         int rc = wf_prepare(s);
