@@ -325,17 +325,24 @@ def test_host_built_scenes_fp64_and_fp32_vs_oracle(R, which, depth):
     hs.free()
 
 
-@pytest.mark.parametrize("which,limit", [("random_spheres", 0.004), ("deep_bounce", 0.010), ("cornell", 0.010)])
-def test_fast_ray_counts_match_fp64_per_pixel(R, which, limit):
+@pytest.mark.parametrize("which,limit", [("random_spheres", 0.004), ("deep_bounce", 0.010), ("cornell", 0.010), ("textured", 0.004), ("mesh", 0.010)])
+def test_fast_ray_counts_match_fp64_per_pixel(R, tmp_path, which, limit):
     """Per-pixel ray counts (RT_FLAG_DEBUG_RAY_COUNTS) of every fp32 kernel variant against the fp64 reference mode on the same
     streams, WITHOUT early exit, so the segments after a specular bounce (rejected by the reference's pdf-0 rule, but still
     traced by it) are covered too.  One wrong ray anywhere changes the number of segments that follow, so this catches what the
     RMSE bars cannot: it is how the scattered-ray corruption described at mat_scatter() (rt_device.h) was found -- 2.7 % / 11 %
     of the pixels differed then, against 0.1 % / 0.3 % of fp32-vs-fp64 silhouette grazes now.  Bars: differing pixels <= 0.4 %
-    (spheres) / 1 % (deep-bounce glass and mirrors, cornell), total rays within 0.05 %."""
+    (spheres, the textured host scene) / 1 % (deep-bounce glass and mirrors, cornell, the OBJ mesh), total rays within 0.05 %.  Between them
+    the scenes run the kernel classes 5 (spheres and rects), 7 (instances), 0 (general) and 3 (OBJ loader)."""
     from raytracing_amd.host_scenes import HostScene
     w, h, spp, depth = 192, 108, 8, 50
-    hs = HostScene.cornell(w, h) if which == "cornell" else getattr(HostScene, which)(w, h, 1)
+    if which == "mesh":                  # the OBJ-loader kernel variant: the generated mesh of bench.py at 5 k triangles
+        from raytracing_amd.tools.make_mesh import write_scene
+        path = str(tmp_path / "blob4.obj")
+        write_scene(path, 4)
+        hs = HostScene.obj(path, w, h, 1, cam_pos=(0, 1.8, 5.0), cam_lookat=(0, 1.0, 0), fov=40.0)
+    else:
+        hs = HostScene.cornell(w, h) if which == "cornell" else getattr(HostScene, which)(w, h, 1)
     sc = hs.upload()
     ref, _, st64 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_REFERENCE_FP64, seed=3, flags=R.FLAG_DEBUG_RAY_COUNTS)
     for name, mode, flags in (("fast", R.MODE_FAST_FP32, 0), ("fast_lanesync", R.MODE_FAST_FP32, R.FLAG_LEGACY_LOOP),
