@@ -177,6 +177,161 @@ def write_ngon_scene(path_obj, path_mtl):
         f.write("\n".join(lines) + "\n")
 
 
+def test_pictures():
+    """Deterministic pictures for the image-file fixture: a smooth colour field (what a texture mostly is), one with hard edges and
+    saturated noise (coefficients that drive the inverse DCT into its clamps), and the small sizes whose planes are narrower
+    than one block."""
+    rng = np.random.default_rng(20260211)
+
+    def field(w, h):
+        y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+        r = 127 + 120 * np.sin(x / 5.0 + y / 11.0)
+        g = 127 + 120 * np.cos(x / 3.0) * np.sin(y / 4.0)
+        b = (x * 7 + y * 13) % 256
+        return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+    def harsh(w, h):
+        img = rng.integers(0, 2, (h, w, 3)) * 255
+        img[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = rng.integers(0, 256, (2 * h // 3 - h // 3, 3 * w // 4 - w // 4, 3))
+        return img.astype(np.uint8)
+    return field, harsh
+
+
+def write_png_by_hand(path, arr, ctype, depth, interlaced):
+    """PNG kinds Pillow does not write (Adam7 interlace, 16-bit RGB / RGBA): filter 0 rows through zlib."""
+    import struct
+    import zlib
+    h, w, ch = arr.shape
+    if depth == 16:                                   # low byte: something that must not show in the 8-bit result
+        wide = np.stack([arr, (arr.astype(np.int32) * 37 % 256).astype(np.uint8)], -1).reshape(h, w, ch * 2)
+    else:
+        wide = arr
+    raw = b""
+    if interlaced:
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = wide[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                for row in sub:
+                    raw += b"\0" + row.tobytes()
+    else:
+        for row in wide:
+            raw += b"\0" + row.tobytes()
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlaced else 0))
+                + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def image_files(tmp):
+    """(name, path) of the files of tests/golden/images.npz, written with Pillow (the fixture keeps the file bytes, so the
+    tests do not depend on Pillow or on its version)."""
+    from PIL import Image
+    field, harsh = test_pictures()
+    out = []
+
+    def save(name, arr, mode=None, **kw):
+        path = os.path.join(tmp, name)
+        im = Image.fromarray(arr) if mode is None else Image.fromarray(arr).convert(mode)
+        im.save(path, **kw)
+        out.append((name, path))
+        return path
+    a, b = field(37, 29), harsh(50, 33)
+    save("rgb444_q90.jpg", a, quality=90, subsampling=0)
+    save("rgb422_q75.jpg", a, quality=75, subsampling=1)
+    save("rgb420_q75.jpg", a, quality=75, subsampling=2)
+    save("rgb420_q30_harsh.jpg", b, quality=30, subsampling=2)
+    save("rgb444_q100_harsh.jpg", b, quality=100, subsampling=0)
+    save("rgb420_q5_harsh.jpg", b, quality=5, subsampling=2)
+    for sub in ("4:1:1", "4:4:0"):
+        try:
+            save("rgb%s_q80.jpg" % sub.replace(":", ""), a, quality=80, subsampling=sub)
+        except Exception as e:                     # an older Pillow: the fixture simply lacks the case
+            print("   (no %s: %s)" % (sub, e))
+    save("rgb420_1x1.jpg", field(1, 1), quality=80, subsampling=2)
+    save("rgb420_1x9.jpg", field(1, 9), quality=80, subsampling=2)
+    save("rgb422_2x2.jpg", field(2, 2), quality=80, subsampling=1)
+    save("rgb420_17x16.jpg", field(17, 16), quality=80, subsampling=2)
+    save("rgb420_200x120.jpg", field(200, 120), quality=85, subsampling=2)
+    save("grey_q85.jpg", a, mode="L", quality=85)
+    save("grey_q20_harsh.jpg", b, mode="L", quality=20)
+    save("prog444.jpg", a, quality=85, subsampling=0, progressive=True)
+    save("prog420.jpg", field(61, 43), quality=70, subsampling=2, progressive=True)
+    save("prog420_harsh.jpg", b, quality=40, subsampling=2, progressive=True)
+    save("prog_grey.jpg", a, mode="L", quality=80, progressive=True)
+    save("optimised420.jpg", a, quality=75, subsampling=2, optimize=True)
+    try:
+        save("restart420.jpg", field(61, 43), quality=75, subsampling=2, restart_marker_blocks=3)
+        save("restart_rows444.jpg", a, quality=75, subsampling=0, restart_marker_rows=1)
+        save("restart_prog420.jpg", field(61, 43), quality=75, subsampling=2, progressive=True, restart_marker_blocks=2)
+    except Exception as e:
+        print("   (no restart markers: %s)" % e)
+    save("cmyk.jpg", a, mode="CMYK", quality=85)
+    # components named 'R','G','B' (stb then skips the colour matrix, stb_image.hpp:3253,3825): patch the ids of a 4:4:4 file
+    p = save("rgb_ids.jpg", a, quality=90, subsampling=0)
+    raw = bytearray(open(p, "rb").read())
+    sof = raw.index(b"\xff\xc0")
+    sos = raw.index(b"\xff\xda")
+    for k, ch in enumerate(b"RGB"):
+        assert raw[sof + 10 + 3 * k] == k + 1 and raw[sos + 5 + 2 * k] == k + 1
+        raw[sof + 10 + 3 * k] = ch
+        raw[sos + 5 + 2 * k] = ch
+    open(p, "wb").write(bytes(raw))
+    # chroma at half height only (4:4:0), which Pillow does not write: a 48x16 4:2:2 file holds 3x2 MCUs of luma-luma-Cb-Cr
+    # blocks; with the luma factors swapped to 1x2 and the size set to 21x27 the same entropy data is 3x2 MCUs of a 4:4:0 frame
+    # (a scrambled picture, which is as good a test of the vertical chroma filter as any)
+    p = save("rgb440_patched.jpg", field(48, 16), quality=80, subsampling=1)
+    raw = bytearray(open(p, "rb").read())
+    sof = raw.index(b"\xff\xc0")
+    assert raw[sof + 11] == 0x21 and raw[sof + 5:sof + 9] == bytes([0, 16, 0, 48])
+    raw[sof + 11] = 0x12
+    raw[sof + 5:sof + 9] = bytes([0, 27, 0, 21])
+    open(p, "wb").write(bytes(raw))
+    # four components read as YCCK (Adobe transform 2) and, with the Adobe segment cut out, as YCbCr plus an ignored plane
+    cmyk = bytearray(open(os.path.join(tmp, "cmyk.jpg"), "rb").read())
+    app14 = cmyk.index(b"\xff\xeeAdobe".replace(b"Adobe", b"\x00\x0eAdobe"))
+    assert cmyk[app14 + 15] == 0
+    ycck = bytearray(cmyk)
+    ycck[app14 + 15] = 2
+    open(os.path.join(tmp, "ycck_patched.jpg"), "wb").write(bytes(ycck))
+    out.append(("ycck_patched.jpg", os.path.join(tmp, "ycck_patched.jpg")))
+    open(os.path.join(tmp, "four_planes_no_adobe.jpg"), "wb").write(bytes(cmyk[:app14] + cmyk[app14 + 16:]))
+    out.append(("four_planes_no_adobe.jpg", os.path.join(tmp, "four_planes_no_adobe.jpg")))
+    # PNG kinds the loader meets
+    save("rgb.png", a)
+    save("rgba.png", np.concatenate([a, a[:, :, :1]], -1))
+    save("grey.png", a, mode="L")
+    save("grey_alpha.png", np.concatenate([a[:, :, :1], a[:, :, 1:2]], -1))
+    save("palette.png", a, mode="P")
+    save("palette16.png", a, mode="P", bits=4)
+    Image.fromarray(a).convert("P").save(os.path.join(tmp, "palette_trns.png"), transparency=3)
+    out.append(("palette_trns.png", os.path.join(tmp, "palette_trns.png")))
+    save("bilevel.png", (a[:, :, 0] > 127).astype(np.uint8) * 255, mode="1")
+    save("rgb_trns.png", a, transparency=(int(a[0, 0, 0]), int(a[0, 0, 1]), int(a[0, 0, 2])))
+    save("grey_trns.png", a, mode="L", transparency=int(np.array(Image.fromarray(a).convert("L"))[2, 2]))
+    Image.fromarray((a[:, :, 0].astype(np.uint16) * 257 + 31)).save(os.path.join(tmp, "grey16.png"))
+    out.append(("grey16.png", os.path.join(tmp, "grey16.png")))
+    for name, arr, ctype, depth in (("interlaced_rgb.png", a, 2, 8), ("interlaced_grey.png", a[:, :, :1], 0, 8), ("rgb16.png", a, 2, 16), ("interlaced_rgba16.png", np.concatenate([a, a[:, :, :1]], -1), 6, 16)):
+        path = os.path.join(tmp, name)
+        write_png_by_hand(path, arr, ctype, depth, interlaced=name.startswith("interlaced"))
+        out.append((name, path))
+    return out
+
+
+def make_images_fixture():
+    with tempfile.TemporaryDirectory() as tmp:
+        files = image_files(tmp)
+        arrays, _ = run(["images"] + [p for _, p in files], tmp)
+        packed = {"names": np.array([n for n, _ in files])}
+        for k, (name, path) in enumerate(files):
+            packed["file%d" % k] = np.fromfile(path, dtype=np.uint8)
+            packed["dims%d" % k] = arrays["img%d_dims" % k]
+            packed["pixels%d" % k] = arrays["img%d_pixels" % k]
+            print("   ", name, packed["dims%d" % k].tolist(), packed["file%d" % k].size, "bytes")
+    np.savez_compressed(os.path.join(GOLD, "images.npz"), **packed)
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -203,6 +358,10 @@ def main():
         "features": (["features", 4, 48, 32, 4, 10], dict(seed=4, width=48, height=32, spp=4, depth=10)),
     }
     only = sys.argv[1:]          # optional: names of the fixtures to (re)generate
+    if not only or "images" in only:
+        # image files as the reference's image texture loads them (texture.hpp:87): file bytes in, texels out
+        print("images")
+        make_images_fixture()
     for name, (args, meta) in jobs.items():
         if only and name not in only:
             continue

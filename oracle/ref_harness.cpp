@@ -729,6 +729,19 @@ int main(int argc, char** argv)
         double t1 = omp_get_wtime();
         printf("INFO time_obj seconds=%f bvh_seconds=%f\n", t1 - t0, t0 - tb);
     }
+    else if (mode == "images") {        // images <file>... : what the reference's image texture holds after loading each file
+        for (int k = 3; k < argc; k++) {
+            int w = 0, h = 0, ch = 0;
+            unsigned char* px = stbi_load(argv[k], &w, &h, &ch, 0);      // texture.hpp:87
+            std::vector<int32_t> dims = { w, h, ch, px ? 1 : 0 };
+            std::vector<uint8_t> bytes;
+            if (px) bytes.assign(px, px + (size_t) w * h * ch);
+            char name[64];
+            snprintf(name, sizeof name, "img%d_dims", k - 3); dump_i32(name, dims);
+            snprintf(name, sizeof name, "img%d_pixels", k - 3); dump_u8(name, bytes);
+            stbi_image_free(px);
+        }
+    }
     else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 1; }
     return 0;
 }

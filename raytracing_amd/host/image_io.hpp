@@ -1,8 +1,9 @@
-// raytracing_amd/host/image_io.hpp -- minimal PNG read/write for the host driver.
+// raytracing_amd/host/image_io.hpp -- image read/write for the host driver.
 // The reference uses the vendored stb_image / stb_image_write (texture.hpp:87, raytracing.cpp:124-125); those are
-// third-party sources this repository does not carry, so the two calls the renderer needs are provided here on
-// top of zlib: 8-bit non-interlaced PNG decode (gray / gray+alpha / RGB / RGBA / palette), binary PPM decode, and
-// PNG encode.  Decoded texels use stb's layout: rows top to bottom, channels interleaved.
+// third-party sources this repository does not carry, so the two calls the renderer needs are provided here: PNG decode on
+// top of zlib (every colour type and bit depth, Adam7 included), JPEG decode (jpeg_decode.hpp: baseline and progressive), binary PPM
+// decode, and PNG encode.  Decoded texels use stb's layout: rows top to bottom, channels interleaved, as many channels as the
+// file holds (the `0` of stbi_load(path, &w, &h, &ch, 0)).
 #pragma once
 
 #include <zlib.h>
@@ -13,6 +14,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include "jpeg_decode.hpp"
 
 inline bool rt_read_file(const char* path, std::vector<unsigned char>& out)
 {
@@ -29,59 +32,123 @@ inline bool rt_read_file(const char* path, std::vector<unsigned char>& out)
 
 inline uint32_t rt_be32(const unsigned char* p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p[1] << 16) | ((uint32_t) p[2] << 8) | p[3]; }
 
+// PNG as stb_image hands it to an 8-bit caller: every colour type and bit depth of the standard, Adam7 interlace included; samples
+// of 1 / 2 / 4 bits scaled to 0..255 (x255, x85, x17), 16-bit samples cut to their high byte; a palette becomes RGB, or RGBA when
+// the file has a tRNS chunk; a grey or RGB file with a tRNS colour key gains an alpha channel of 0 / 255 (the key is compared at
+// the file's own depth).  tests/golden/images.npz pins it against the reference's loader.
 inline bool rt_decode_png(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
 {
     static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
     if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) return false;
     size_t pos = 8;
     int depth = 0, color = 0, interlace = 0;
-    std::vector<unsigned char> idat, palette;
+    bool have_key = false;
+    std::vector<unsigned char> idat, palette, trns;
     while (pos + 12 <= file.size()) {
         uint32_t len = rt_be32(&file[pos]);
         const unsigned char* type = &file[pos + 4];
         const unsigned char* body = &file[pos + 8];
         if (pos + 12 + (size_t) len > file.size()) return false;
-        if (!std::memcmp(type, "IHDR", 4)) { w = (int) rt_be32(body); h = (int) rt_be32(body + 4); depth = body[8]; color = body[9]; interlace = body[12]; }
+        if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = (int) rt_be32(body); h = (int) rt_be32(body + 4); depth = body[8]; color = body[9]; interlace = body[12]; }
         else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) { trns.assign(body, body + len); have_key = true; }
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t) len;
     }
-    if (depth != 8 || interlace != 0 || w <= 0 || h <= 0) return false;
     int src_ch = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
-    if (!src_ch) return false;
-    size_t stride = (size_t) w * src_ch;
-    std::vector<unsigned char> raw((stride + 1) * h);
+    bool depth_ok = color == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                  : color == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8) : (depth == 8 || depth == 16);
+    if (!src_ch || !depth_ok || interlace > 1 || w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28)) return false;
+    if (color == 3 && palette.empty()) return false;
+    if (color == 4 || color == 6) have_key = false;          // files with an alpha channel carry no key
+
+    // the passes of the picture: one, or Adam7's seven sub-pictures
+    struct pass { int x0, y0, dx, dy; };
+    static const pass whole[1] = { { 0, 0, 1, 1 } };
+    static const pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    const pass* passes = interlace ? adam7 : whole;
+    int n_pass = interlace ? 7 : 1;
+    int bits_px = src_ch * depth, filter_bytes = bits_px >= 8 ? bits_px / 8 : 1;
+    size_t total = 0;
+    for (int p = 0; p < n_pass; p++) {
+        int pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+        if (pw > 0 && ph > 0) total += (((size_t) pw * bits_px + 7) / 8 + 1) * ph;
+    }
+    std::vector<unsigned char> raw(total);
     uLongf raw_len = (uLongf) raw.size();
-    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size()) != Z_OK || raw_len != raw.size()) return false;
-    std::vector<unsigned char> img(stride * h);
-    for (int y = 0; y < h; y++) {
-        const unsigned char* in = &raw[(stride + 1) * y];
-        unsigned char* cur = &img[stride * y];
-        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        int filter = in[0];
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= (size_t) src_ch ? cur[x - src_ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t) src_ch) ? up[x - src_ch] : 0;
-            int v = in[1 + x];
-            switch (filter) {
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-            default: break;
+    int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size());
+    if ((zr != Z_OK && zr != Z_BUF_ERROR) || raw_len < raw.size()) return false;     // stb tolerates bytes after the last row
+
+    std::vector<uint16_t> samples((size_t) w * h * src_ch);                          // as stored, before any scaling
+    size_t at = 0;
+    std::vector<unsigned char> prev, cur;
+    for (int p = 0; p < n_pass; p++) {
+        int pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+        if (pw <= 0 || ph <= 0) continue;
+        size_t stride = ((size_t) pw * bits_px + 7) / 8;
+        prev.assign(stride, 0);
+        cur.assign(stride, 0);
+        for (int y = 0; y < ph; y++) {
+            const unsigned char* in = &raw[at];
+            at += stride + 1;
+            int filter = in[0];
+            if (filter > 4) return false;
+            for (size_t x = 0; x < stride; x++) {
+                int a = x >= (size_t) filter_bytes ? cur[x - filter_bytes] : 0, b = prev[x], c = x >= (size_t) filter_bytes ? prev[x - filter_bytes] : 0;
+                int v = in[1 + x];
+                switch (filter) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: { int q = a + b - c, pa = std::abs(q - a), pb = std::abs(q - b), pc = std::abs(q - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: break;
+                }
+                cur[x] = (unsigned char) v;
             }
-            cur[x] = (unsigned char) v;
+            uint16_t* out_row = &samples[((size_t) (passes[p].y0 + y * passes[p].dy) * w) * src_ch];
+            for (int x = 0; x < pw; x++) {
+                uint16_t* out = out_row + (size_t) (passes[p].x0 + x * passes[p].dx) * src_ch;
+                for (int k = 0; k < src_ch; k++) {
+                    size_t i = (size_t) x * src_ch + k;
+                    if (depth == 8) out[k] = cur[i];
+                    else if (depth == 16) out[k] = (uint16_t) ((cur[2 * i] << 8) | cur[2 * i + 1]);
+                    else { size_t bit = i * depth; out[k] = (uint16_t) ((cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)); }
+                }
+            }
+            prev.swap(cur);
         }
     }
-    if (color == 3) {   // palette -> RGB
-        ch = 3;
-        pixels.resize((size_t) w * h * 3);
-        for (size_t i = 0; i < (size_t) w * h; i++) {
-            size_t k = (size_t) img[i] * 3;
-            for (int c = 0; c < 3; c++) pixels[i * 3 + c] = k + c < palette.size() ? palette[k + c] : 0;
+
+    size_t n_px = (size_t) w * h;
+    if (color == 3) {
+        ch = have_key ? 4 : 3;
+        pixels.resize(n_px * ch);
+        for (size_t i = 0; i < n_px; i++) {
+            size_t k = samples[i];
+            for (int c = 0; c < 3; c++) pixels[i * ch + c] = k * 3 + c < palette.size() ? palette[k * 3 + c] : 0;
+            if (have_key) pixels[i * 4 + 3] = k < trns.size() ? trns[k] : 255;
         }
+        return true;
     }
-    else { ch = src_ch; pixels.swap(img); }
+    int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
+    if (have_key && trns.size() < (size_t) src_ch * 2) have_key = false;
+    ch = src_ch + (have_key ? 1 : 0);
+    pixels.resize(n_px * ch);
+    for (size_t i = 0; i < n_px; i++) {
+        bool is_key = have_key;
+        for (int k = 0; k < src_ch; k++) {
+            uint16_t v = samples[i * src_ch + k];
+            unsigned key = (unsigned) ((trns.size() >= (size_t) k * 2 + 2) ? (trns[2 * k] << 8) | trns[2 * k + 1] : 0);
+            if (depth == 16) { is_key = is_key && v == key; pixels[i * ch + k] = (unsigned char) (v >> 8); }
+            else {
+                unsigned char v8 = (unsigned char) (v * scale);
+                is_key = is_key && v8 == (unsigned char) ((key & 255) * scale);
+                pixels[i * ch + k] = v8;
+            }
+        }
+        if (have_key) pixels[i * ch + src_ch] = is_key ? 0 : 255;
+    }
     return true;
 }
 
@@ -94,13 +161,13 @@ inline bool rt_decode_ppm(const std::vector<unsigned char>& file, std::vector<un
         while (pos < file.size() && (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t')) pos++;
         if (pos < file.size() && file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; continue; }
         int v = 0; bool any = false;
-        while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') { v = v * 10 + (file[pos] - '0'); pos++; any = true; }
+        while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') { if (v < (1 << 24)) v = v * 10 + (file[pos] - '0'); pos++; any = true; }
         if (!any) return false;
         vals[got++] = v;
     }
     pos++;
     w = vals[0]; h = vals[1]; ch = 3;
-    if (got < 3 || vals[2] != 255 || pos + (size_t) w * h * 3 > file.size()) return false;
+    if (got < 3 || vals[2] != 255 || w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28) || pos + (size_t) w * h * 3 > file.size()) return false;
     pixels.assign(file.begin() + pos, file.begin() + pos + (size_t) w * h * 3);
     return true;
 }
@@ -109,7 +176,7 @@ inline bool rt_load_image(const char* path, std::vector<unsigned char>& pixels, 
 {
     std::vector<unsigned char> file;
     if (!rt_read_file(path, file)) return false;
-    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_ppm(file, pixels, w, h, ch);
+    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_jpeg(file, pixels, w, h, ch) || rt_decode_ppm(file, pixels, w, h, ch);   // stb tries them in this order
 }
 
 // 8-bit RGB/RGBA/gray PNG.  flip_vertically mirrors stbi_flip_vertically_on_write(true) (raytracing.cpp:124): the

@@ -1,0 +1,562 @@
+// raytracing_amd/host/jpeg_decode.hpp -- JPEG decode for image textures (map_Kd *.jpg).
+// The reference loads textures with the vendored stb_image (texture.hpp:87, stbi_load(path, &w, &h, &ch, 0)); that third-party
+// source is not carried here.  This is a decoder of ITU-T T.81 streams -- baseline and extended sequential Huffman (SOF0/SOF1),
+// progressive Huffman (SOF2), restart intervals, 1 / 3 / 4 components, any integer sampling ratio -- whose sample arithmetic
+// restates the choices stb_image makes, because a texel that differs by one changes a rendered image: the 12-bit fixed-point
+// "islow" inverse DCT with its two rounding points (stb_image.hpp:2392-2490), the centred triangle filter for 2x chroma planes and
+// replication for other ratios (:3411-3473, :3592-3601), the row stepping of the vertical filter (:3853-3886), the 12-bit YCbCr
+// matrix with the truncated green term (:3605-3629), and the Adobe CMYK / YCCK rules (:3902-3923).  tests/golden/images.npz pins
+// it byte for byte against the reference's loader on baseline / progressive / subsampled / restart / grey / CMYK files.
+// Not decoded (stb does not either): arithmetic coding, lossless and hierarchical frames, 12-bit samples.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace rtjpeg {
+
+// natural (row-major) position of the k-th coefficient of the zig-zag scan (T.81 figure A.6)
+static const unsigned char k_natural[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+
+struct huffman {                 // canonical code of T.81 annex C: codes of one length are consecutive
+    int first[17] = { 0 };       // first code of each length
+    int count[17] = { 0 };
+    int base[17] = { 0 };        // index of that code's symbol in `symbol`
+    unsigned char symbol[256] = { 0 };
+    bool defined = false;
+};
+
+struct component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int pred = 0;                // DC predictor
+    int cols = 0, rows = 0;      // samples this component really has
+    int stride = 0, lines = 0;   // plane size, whole MCUs
+    int blocks_w = 0;
+    std::vector<unsigned char> plane;
+    std::vector<short> coeff;    // progressive frames keep every block's coefficients until the last scan
+};
+
+struct decoder {
+    const unsigned char* data = nullptr;
+    size_t size = 0, pos = 0;
+    // entropy-coded segment reader: bits enter `window` from the top; a marker inside the segment stops the bytes and feeds zeros
+    uint32_t window = 0;
+    int held = 0;
+    int pending_marker = 0;
+
+    huffman dc_table[4], ac_table[4];
+    uint16_t quant[4][64] = { { 0 } };      // natural order
+    component comp[4];
+    int n_comp = 0, width = 0, height = 0, h_max = 1, v_max = 1, mcus_x = 0, mcus_y = 0;
+    bool progressive = false, have_frame = false, jfif = false;
+    int adobe_transform = -1, rgb_ids = 0;
+    int restart_interval = 0, until_restart = 0, eob_run = 0;
+    int scan_n = 0, scan_comp[4] = { 0 }, ss = 0, se = 63, ah = 0, al = 0;
+
+    int byte() { return pos < size ? data[pos++] : 0; }
+    int word() { int hi = byte(); return (hi << 8) | byte(); }
+
+    void refill()
+    {
+        while (held <= 24) {
+            int b = 0;
+            if (!pending_marker) {
+                b = byte();
+                if (b == 0xff) {
+                    int c = byte();
+                    while (c == 0xff) c = byte();
+                    if (c) { pending_marker = c; b = 0; }
+                }
+            }
+            window |= (uint32_t) b << (24 - held);
+            held += 8;
+        }
+    }
+    int bits(int n)              // n <= 16
+    {
+        if (n == 0) return 0;
+        if (held < n) refill();
+        int v = (int) (window >> (32 - n));
+        window <<= n;
+        held -= n;
+        return v;
+    }
+    static int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }   // T.81 F.2.2.1
+    int receive_extend(int n) { return n ? extend(bits(n), n) : 0; }
+
+    int decode(const huffman& t)
+    {
+        if (held < 16) refill();
+        unsigned top = window >> 16;
+        for (int len = 1; len <= 16; len++) {
+            unsigned code = top >> (16 - len);
+            if ((unsigned) (code - t.first[len]) < (unsigned) t.count[len]) {
+                window <<= len;
+                held -= len;
+                return t.symbol[t.base[len] + (int) code - t.first[len]];
+            }
+        }
+        return -1;
+    }
+
+    void reset_entropy()
+    {
+        window = 0; held = 0; pending_marker = 0; eob_run = 0;
+        for (auto& c : comp) c.pred = 0;
+        until_restart = restart_interval ? restart_interval : 0x7fffffff;
+    }
+    // after each MCU: true = go on, false = the segment is over (a restart was due and none came)
+    bool mcu_done()
+    {
+        if (--until_restart > 0) return true;
+        if (held < 24) refill();
+        if (pending_marker < 0xd0 || pending_marker > 0xd7) return false;
+        reset_entropy();
+        return true;
+    }
+
+    // ---- tables and headers
+    bool read_quant()
+    {
+        int len = word() - 2;
+        while (len > 0) {
+            int pq_tq = byte(), wide = pq_tq >> 4, t = pq_tq & 15;
+            if (wide > 1 || t > 3) return false;
+            for (int k = 0; k < 64; k++) quant[t][k_natural[k]] = (uint16_t) (wide ? word() : byte());
+            len -= wide ? 129 : 65;
+        }
+        return len == 0;
+    }
+    bool read_huffman()
+    {
+        int len = word() - 2;
+        while (len > 0) {
+            int tc_th = byte(), cls = tc_th >> 4, t = tc_th & 15;
+            if (cls > 1 || t > 3) return false;
+            huffman& h = cls ? ac_table[t] : dc_table[t];
+            int total = 0, code = 0;
+            for (int l = 1; l <= 16; l++) { h.count[l] = byte(); }
+            for (int l = 1; l <= 16; l++) {
+                h.first[l] = code; h.base[l] = total;
+                code += h.count[l]; total += h.count[l];
+                if (code > (1 << l)) return false;
+                code <<= 1;
+            }
+            if (total > 256) return false;
+            for (int i = 0; i < total; i++) h.symbol[i] = (unsigned char) byte();
+            h.defined = true;
+            len -= 17 + total;
+        }
+        return len == 0;
+    }
+    bool read_application(int marker)
+    {
+        int len = word();
+        if (len < 2) return false;
+        len -= 2;
+        if (marker == 0xe0 && len >= 5) {
+            static const char tag[5] = { 'J', 'F', 'I', 'F', 0 };
+            bool same = true;
+            for (int i = 0; i < 5; i++) same &= byte() == (unsigned char) tag[i];
+            len -= 5;
+            if (same) jfif = true;
+        }
+        else if (marker == 0xee && len >= 12) {
+            static const char tag[6] = { 'A', 'd', 'o', 'b', 'e', 0 };
+            bool same = true;
+            for (int i = 0; i < 6; i++) same &= byte() == (unsigned char) tag[i];
+            len -= 6;
+            if (same) { byte(); word(); word(); adobe_transform = byte(); len -= 6; }
+        }
+        pos += (size_t) len;
+        return pos <= size;
+    }
+    bool read_frame(int marker)
+    {
+        if (have_frame) return false;
+        progressive = marker == 0xc2;
+        int len = word();
+        if (byte() != 8) return false;                       // 8-bit samples only
+        height = word(); width = word();
+        n_comp = byte();
+        if (height <= 0 || width <= 0 || (n_comp != 1 && n_comp != 3 && n_comp != 4) || len != 8 + 3 * n_comp) return false;
+        if ((uint64_t) width * height > (1ull << 28)) return false;
+        h_max = v_max = 1; rgb_ids = 0;
+        for (int i = 0; i < n_comp; i++) {
+            component& c = comp[i];
+            c.id = byte();
+            if (n_comp == 3 && c.id == "RGB"[i]) rgb_ids++;
+            int hv = byte();
+            c.h = hv >> 4; c.v = hv & 15; c.tq = byte();
+            if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return false;
+            if (c.h > h_max) h_max = c.h;
+            if (c.v > v_max) v_max = c.v;
+        }
+        for (int i = 0; i < n_comp; i++) if (h_max % comp[i].h || v_max % comp[i].v) return false;   // integer ratios only
+        mcus_x = (width + 8 * h_max - 1) / (8 * h_max);
+        mcus_y = (height + 8 * v_max - 1) / (8 * v_max);
+        for (int i = 0; i < n_comp; i++) {
+            component& c = comp[i];
+            c.cols = (width * c.h + h_max - 1) / h_max;
+            c.rows = (height * c.v + v_max - 1) / v_max;
+            c.stride = mcus_x * c.h * 8;
+            c.lines = mcus_y * c.v * 8;
+            c.blocks_w = c.stride / 8;
+            c.plane.assign((size_t) c.stride * c.lines, 0);
+            if (progressive) c.coeff.assign((size_t) c.stride * c.lines, 0);
+        }
+        have_frame = true;
+        return true;
+    }
+    bool read_scan_header()
+    {
+        if (!have_frame) return false;
+        int len = word();
+        scan_n = byte();
+        if (scan_n < 1 || scan_n > n_comp || len != 6 + 2 * scan_n) return false;
+        for (int i = 0; i < scan_n; i++) {
+            int id = byte(), tables = byte(), which = 0;
+            while (which < n_comp && comp[which].id != id) which++;
+            if (which == n_comp) return false;
+            comp[which].td = tables >> 4; comp[which].ta = tables & 15;
+            if (comp[which].td > 3 || comp[which].ta > 3) return false;
+            scan_comp[i] = which;
+        }
+        ss = byte(); se = byte();
+        int a = byte();
+        ah = a >> 4; al = a & 15;
+        if (progressive) { if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return false; }
+        else { if (ss != 0 || ah != 0 || al != 0) return false; se = 63; }
+        return true;
+    }
+
+    // ---- inverse DCT: two passes of the 1-D transform below over int32, constants in 12-bit fixed point; the column pass keeps
+    // two extra bits (+512 >> 10), the row pass removes 17 (+65536, and the +128 level shift folded in) and clamps.
+    static void idct_1d(const int s[8], int even[4], int odd[4])
+    {
+        int p = (s[2] + s[6]) * 2217;
+        int e2 = p + s[6] * -7567, e3 = p + s[2] * 3135;
+        int e0 = (s[0] + s[4]) * 4096, e1 = (s[0] - s[4]) * 4096;
+        even[0] = e0 + e3; even[3] = e0 - e3; even[1] = e1 + e2; even[2] = e1 - e2;
+        int a = s[7], b = s[5], c = s[3], d = s[1];
+        int ac = a + c, bd = b + d, ad = a + d, bc = b + c;
+        int q = (ac + bd) * 4816;
+        a *= 1223; b *= 8410; c *= 12586; d *= 6149;
+        ad = q + ad * -3685; bc = q + bc * -10497;
+        ac *= -8034; bd *= -1597;
+        odd[3] = d + ad + bd; odd[2] = c + bc + ac; odd[1] = b + bc + bd; odd[0] = a + ad + ac;
+    }
+    static unsigned char clamp8(int v) { return (unsigned char) (v < 0 ? 0 : v > 255 ? 255 : v); }
+    static void idct_block(unsigned char* out, int stride, const short in[64])
+    {
+        int mid[64];
+        for (int x = 0; x < 8; x++) {
+            int s[8], e[4], o[4];
+            for (int k = 0; k < 8; k++) s[k] = in[k * 8 + x];
+            idct_1d(s, e, o);
+            for (int k = 0; k < 4; k++) {
+                mid[k * 8 + x] = (e[k] + 512 + o[3 - k]) >> 10;
+                mid[(7 - k) * 8 + x] = (e[k] + 512 - o[3 - k]) >> 10;
+            }
+        }
+        for (int y = 0; y < 8; y++) {
+            int e[4], o[4];
+            idct_1d(&mid[y * 8], e, o);
+            unsigned char* row = out + (size_t) stride * y;
+            const int bias = 65536 + (128 << 17);
+            for (int k = 0; k < 4; k++) {
+                row[k] = clamp8((e[k] + bias + o[3 - k]) >> 17);
+                row[7 - k] = clamp8((e[k] + bias - o[3 - k]) >> 17);
+            }
+        }
+    }
+
+    // ---- entropy-coded blocks
+    bool sequential_block(component& c, short blk[64])
+    {
+        const huffman& dc = dc_table[c.td];
+        const huffman& ac = ac_table[c.ta];
+        const uint16_t* q = quant[c.tq];
+        std::memset(blk, 0, 64 * sizeof(short));
+        int t = decode(dc);
+        if (t < 0 || t > 15) return false;
+        c.pred += receive_extend(t);
+        blk[0] = (short) (c.pred * q[0]);
+        for (int k = 1; k < 64;) {
+            int rs = decode(ac);
+            if (rs < 0) return false;
+            int run = rs >> 4, size = rs & 15;
+            if (size == 0) {
+                if (run != 15) break;            // end of block
+                k += 16;
+                continue;
+            }
+            k += run;
+            if (k > 63) return false;
+            int at = k_natural[k++];
+            blk[at] = (short) (receive_extend(size) * q[at]);
+        }
+        return true;
+    }
+    bool progressive_dc(component& c, short* blk)
+    {
+        if (se != 0) return false;
+        if (ah == 0) {
+            std::memset(blk, 0, 64 * sizeof(short));
+            int t = decode(dc_table[c.td]);
+            if (t < 0 || t > 15) return false;
+            c.pred += receive_extend(t);
+            blk[0] = (short) (c.pred * (1 << al));
+        }
+        else if (bits(1)) blk[0] = (short) (blk[0] + (1 << al));
+        return true;
+    }
+    // one correction bit for a coefficient that is already non-zero (T.81 G.1.2.3)
+    void refine(short& v, int bit)
+    {
+        if (bits(1) && (v & bit) == 0) v = (short) (v > 0 ? v + bit : v - bit);
+    }
+    bool progressive_ac(component& c, short* blk)
+    {
+        if (ss == 0) return false;
+        const huffman& ac = ac_table[c.ta];
+        if (ah == 0) {                                   // first pass over this band
+            if (eob_run) { eob_run--; return true; }
+            for (int k = ss; k <= se;) {
+                int rs = decode(ac);
+                if (rs < 0) return false;
+                int run = rs >> 4, size = rs & 15;
+                if (size == 0) {
+                    if (run < 15) { eob_run = (1 << run) + bits(run) - 1; break; }
+                    k += 16;
+                    continue;
+                }
+                k += run;
+                if (k > 63) return false;
+                blk[k_natural[k++]] = (short) (receive_extend(size) * (1 << al));
+            }
+            return true;
+        }
+        int bit = 1 << al;                               // later passes: one more bit of every coefficient of the band
+        if (eob_run) {
+            eob_run--;
+            for (int k = ss; k <= se; k++) { short& v = blk[k_natural[k]]; if (v) refine(v, bit); }
+            return true;
+        }
+        for (int k = ss; k <= se;) {
+            int rs = decode(ac);
+            if (rs < 0) return false;
+            int run = rs >> 4, size = rs & 15, fresh = 0;
+            if (size == 0) {
+                if (run < 15) { eob_run = (1 << run) + bits(run) - 1; run = 64; }   // the rest of the band only gets corrections
+            }
+            else {
+                if (size != 1) return false;
+                fresh = bits(1) ? bit : -bit;
+            }
+            while (k <= se) {                            // skip `run` zero coefficients, correcting the non-zero ones passed
+                short& v = blk[k_natural[k++]];
+                if (v) refine(v, bit);
+                else if (run == 0) { v = (short) fresh; break; }
+                else run--;
+            }
+        }
+        return true;
+    }
+
+    bool scan_block(component& c, int bx, int by)
+    {
+        if (!progressive) {
+            short blk[64];
+            if (!sequential_block(c, blk)) return false;
+            idct_block(&c.plane[(size_t) c.stride * by * 8 + bx * 8], c.stride, blk);
+            return true;
+        }
+        short* blk = &c.coeff[64 * ((size_t) bx + (size_t) by * c.blocks_w)];
+        return ss == 0 ? progressive_dc(c, blk) : progressive_ac(c, blk);
+    }
+    bool read_scan()
+    {
+        for (int i = 0; i < scan_n; i++) {
+            const component& c = comp[scan_comp[i]];
+            bool needs_dc = !progressive || (ss == 0 && ah == 0), needs_ac = !progressive || ss > 0;
+            if ((needs_dc && !dc_table[c.td].defined) || (needs_ac && !ac_table[c.ta].defined)) return false;
+        }
+        reset_entropy();
+        if (scan_n == 1) {                               // one component: its blocks in raster order, only those that hold samples
+            component& c = comp[scan_comp[0]];
+            int bw = (c.cols + 7) >> 3, bh = (c.rows + 7) >> 3;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    if (!scan_block(c, bx, by)) return false;
+                    if (!mcu_done()) return true;
+                }
+            return true;
+        }
+        if (progressive && ss != 0) return false;        // AC bands are never interleaved
+        for (int my = 0; my < mcus_y; my++)
+            for (int mx = 0; mx < mcus_x; mx++) {
+                for (int i = 0; i < scan_n; i++) {
+                    component& c = comp[scan_comp[i]];
+                    for (int y = 0; y < c.v; y++)
+                        for (int x = 0; x < c.h; x++)
+                            if (!scan_block(c, mx * c.h + x, my * c.v + y)) return false;
+                }
+                if (!mcu_done()) return true;
+            }
+        return true;
+    }
+    void finish_progressive()
+    {
+        for (int i = 0; i < n_comp; i++) {
+            component& c = comp[i];
+            int bw = (c.cols + 7) >> 3, bh = (c.rows + 7) >> 3;
+            for (int by = 0; by < bh; by++)
+                for (int bx = 0; bx < bw; bx++) {
+                    short* blk = &c.coeff[64 * ((size_t) bx + (size_t) by * c.blocks_w)];
+                    for (int k = 0; k < 64; k++) blk[k] = (short) (blk[k] * quant[c.tq][k]);
+                    idct_block(&c.plane[(size_t) c.stride * by * 8 + bx * 8], c.stride, blk);
+                }
+        }
+    }
+
+    int next_marker()
+    {
+        if (pending_marker) { int m = pending_marker; pending_marker = 0; return m; }
+        while (pos < size) {
+            if (byte() != 0xff) continue;
+            int m = byte();
+            while (m == 0xff) m = byte();
+            if (m) return m;
+        }
+        return -1;
+    }
+    bool read_stream()
+    {
+        if (size < 4 || data[0] != 0xff || data[1] != 0xd8) return false;
+        pos = 2;
+        bool any_scan = false;
+        for (;;) {
+            int m = next_marker();
+            if (m < 0) return false;
+            if (m == 0xd9) break;
+            bool ok;
+            if (m == 0xdb) ok = read_quant();
+            else if (m == 0xc4) ok = read_huffman();
+            else if (m == 0xdd) { ok = word() == 4; restart_interval = word(); }
+            else if (m == 0xc0 || m == 0xc1 || m == 0xc2) ok = read_frame(m);
+            else if (m == 0xda) { ok = read_scan_header() && read_scan(); any_scan = true; }
+            else if (m == 0xdc) { ok = word() == 4; ok = (word() == height) && ok; }
+            else if ((m >= 0xe0 && m <= 0xef) || m == 0xfe) ok = read_application(m);
+            else ok = false;                             // arithmetic coding, lossless / hierarchical frames, stray markers
+            if (!ok) return false;
+        }
+        if (!have_frame || !any_scan) return false;
+        if (progressive) finish_progressive();
+        return true;
+    }
+
+    // ---- planes -> interleaved pixels
+    static const unsigned char* upsample_row(unsigned char* out, const unsigned char* near, const unsigned char* far, int w, int hs, int vs)
+    {
+        if (hs == 1 && vs == 1) return near;
+        if (hs == 1 && vs == 2) { for (int i = 0; i < w; i++) out[i] = (unsigned char) ((3 * near[i] + far[i] + 2) >> 2); return out; }
+        if (hs == 2 && vs == 1) {
+            if (w == 1) { out[0] = out[1] = near[0]; return out; }
+            out[0] = near[0];
+            out[1] = (unsigned char) ((near[0] * 3 + near[1] + 2) >> 2);
+            for (int i = 1; i < w - 1; i++) {
+                int n = 3 * near[i] + 2;
+                out[2 * i] = (unsigned char) ((n + near[i - 1]) >> 2);
+                out[2 * i + 1] = (unsigned char) ((n + near[i + 1]) >> 2);
+            }
+            out[2 * w - 2] = (unsigned char) ((near[w - 2] * 3 + near[w - 1] + 2) >> 2);
+            out[2 * w - 1] = near[w - 1];
+            return out;
+        }
+        if (hs == 2 && vs == 2) {
+            int cur = 3 * near[0] + far[0];
+            if (w == 1) { out[0] = out[1] = (unsigned char) ((cur + 2) >> 2); return out; }
+            out[0] = (unsigned char) ((cur + 2) >> 2);
+            for (int i = 1; i < w; i++) {
+                int prev = cur;
+                cur = 3 * near[i] + far[i];
+                out[2 * i - 1] = (unsigned char) ((3 * prev + cur + 8) >> 4);
+                out[2 * i] = (unsigned char) ((3 * cur + prev + 8) >> 4);
+            }
+            out[2 * w - 1] = (unsigned char) ((cur + 2) >> 2);
+            return out;
+        }
+        for (int i = 0; i < w; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = near[i];
+        return out;
+    }
+    static void ycc_to_rgb(unsigned char* out, int y, int cb, int cr)
+    {
+        int base = (y << 20) + (1 << 19);
+        cr -= 128; cb -= 128;
+        int r = base + cr * 1470208;
+        int g = base + cr * -748800 + (int) ((uint32_t) (cb * -360960) & 0xffff0000u);
+        int b = base + cb * 1858048;
+        out[0] = clamp8(r >> 20); out[1] = clamp8(g >> 20); out[2] = clamp8(b >> 20);
+    }
+    static unsigned char scale8(int x, int y) { unsigned t = (unsigned) (x * y + 128); return (unsigned char) ((t + (t >> 8)) >> 8); }
+
+    void emit(std::vector<unsigned char>& pixels, int& channels)
+    {
+        channels = n_comp >= 3 ? 3 : 1;
+        bool is_rgb = n_comp == 3 && (rgb_ids == 3 || (adobe_transform == 0 && !jfif));
+        pixels.assign((size_t) width * height * channels, 0);
+        struct stepper { int hs, vs, step, row, w; const unsigned char* line0; const unsigned char* line1; std::vector<unsigned char> buf; } st[4];
+        for (int k = 0; k < n_comp; k++) {
+            stepper& s = st[k];
+            s.hs = h_max / comp[k].h; s.vs = v_max / comp[k].v;
+            s.step = s.vs >> 1; s.row = 0;
+            s.w = (width + s.hs - 1) / s.hs;
+            s.line0 = s.line1 = comp[k].plane.data();
+            s.buf.assign((size_t) s.w * s.hs + 8, 0);
+        }
+        for (int j = 0; j < height; j++) {
+            const unsigned char* row[4] = { nullptr, nullptr, nullptr, nullptr };
+            for (int k = 0; k < n_comp; k++) {
+                stepper& s = st[k];
+                bool lower = s.step >= (s.vs >> 1);
+                row[k] = upsample_row(s.buf.data(), lower ? s.line1 : s.line0, lower ? s.line0 : s.line1, s.w, s.hs, s.vs);
+                if (++s.step >= s.vs) {
+                    s.step = 0;
+                    s.line0 = s.line1;
+                    if (++s.row < comp[k].rows) s.line1 += comp[k].stride;
+                }
+            }
+            unsigned char* out = &pixels[(size_t) width * channels * j];
+            for (int i = 0; i < width; i++, out += channels) {
+                if (n_comp == 1) out[0] = row[0][i];
+                else if (n_comp == 3) {
+                    if (is_rgb) { out[0] = row[0][i]; out[1] = row[1][i]; out[2] = row[2][i]; }
+                    else ycc_to_rgb(out, row[0][i], row[1][i], row[2][i]);
+                }
+                else if (adobe_transform == 0) {          // CMYK
+                    for (int c = 0; c < 3; c++) out[c] = scale8(row[c][i], row[3][i]);
+                }
+                else {
+                    ycc_to_rgb(out, row[0][i], row[1][i], row[2][i]);
+                    if (adobe_transform == 2) for (int c = 0; c < 3; c++) out[c] = scale8(255 - out[c], row[3][i]);   // YCCK
+                }
+            }
+        }
+    }
+};
+
+}   // namespace rtjpeg
+
+inline bool rt_decode_jpeg(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    rtjpeg::decoder d;
+    d.data = file.data(); d.size = file.size();
+    if (!d.read_stream()) return false;
+    d.emit(pixels, ch);
+    w = d.width; h = d.height;
+    return true;
+}

@@ -211,6 +211,24 @@ rth_scene* rth_build_textured(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// What an image texture holds after loading `path` (texture.hpp:87: stbi_load with 0 requested channels): size and channel
+// count as in the file, texels top row first.  Returns the byte count w*h*ch and copies the texels when `capacity` holds
+// them (call once with capacity 0 for the size); -1 with rth_last_error set when the file cannot be decoded.
+long long rth_load_image(const char* path, int* w, int* h, int* channels, unsigned char* texels, unsigned long long capacity)
+{
+    try {
+        std::vector<unsigned char> px;
+        int iw = 0, ih = 0, ich = 0;
+        if (!path || !rt_load_image(path, px, iw, ih, ich)) { g_err = std::string("can not load image: ") + (path ? path : "(null)"); return -1; }
+        if (w) *w = iw;
+        if (h) *h = ih;
+        if (channels) *channels = ich;
+        if (texels && capacity >= px.size()) std::memcpy(texels, px.data(), px.size());
+        return (long long) px.size();
+    }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
 const rt_scene_desc* rth_desc(const rth_scene* s) { return s ? &s->desc : nullptr; }
 void rth_free(rth_scene* s) { delete s; }
 

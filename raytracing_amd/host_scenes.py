@@ -33,8 +33,24 @@ def load_host_library():
         L.rth_desc.restype = C.POINTER(SceneDesc)
         L.rth_desc.argtypes = [C.c_void_p]
         L.rth_free.argtypes = [C.c_void_p]
+        L.rth_load_image.restype = C.c_longlong
+        L.rth_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_ulonglong]
         _lib = L
     return _lib
+
+
+def load_image(path):
+    """The texels an image texture holds after loading `path` (PNG, JPEG or PPM), as the reference's loader hands them over
+    (texture.hpp:87): uint8 array of shape (height, width, channels), top row first."""
+    L = load_host_library()
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    n = L.rth_load_image(path.encode(), C.byref(w), C.byref(h), C.byref(ch), None, 0)
+    if n < 0:
+        raise RtError(L.rth_last_error().decode())
+    out = np.zeros(n, np.uint8)
+    if L.rth_load_image(path.encode(), C.byref(w), C.byref(h), C.byref(ch), out.ctypes.data_as(C.c_void_p), n) != n:
+        raise RtError(L.rth_last_error().decode())
+    return out.reshape(h.value, w.value, ch.value)
 
 
 class HostScene:
