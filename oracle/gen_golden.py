@@ -316,6 +316,90 @@ def image_files(tmp):
         path = os.path.join(tmp, name)
         write_png_by_hand(path, arr, ctype, depth, interlaced=name.startswith("interlaced"))
         out.append((name, path))
+    # BMP, TGA, PGM / PPM: the other stb formats an MTL file may name
+    import struct
+    pal_img = Image.fromarray(a).convert("P")
+    pal = np.zeros((256, 3), np.uint8)
+    flat = np.array(pal_img.getpalette()[:768], np.uint8)
+    pal.reshape(-1)[:flat.size] = flat
+    idx = np.array(pal_img)
+    grey = np.array(Image.fromarray(a).convert("L"))
+    rgba = np.concatenate([a, a[:, :, 1:2]], -1)
+    save("rgb.bmp", a)
+    save("rgba.bmp", rgba)
+    save("palette.bmp", a, mode="P")
+    save("grey.bmp", a, mode="L")
+    save("bilevel.bmp", (a[:, :, 0] > 127).astype(np.uint8) * 255, mode="1")
+
+    def raw_file(name, data):
+        path = os.path.join(tmp, name)
+        open(path, "wb").write(data)
+        out.append((name, path))
+
+    def bmp(name, hsz, bpp, rows, palette=b"", compress=0, masks=b"", top_down=False):
+        hh, ww = len(rows), None
+        body = b"".join(r + b"\0" * ((-len(r)) & 3) for r in (rows if top_down else rows[::-1]))
+        ww = a.shape[1]
+        if hsz == 12:
+            info = struct.pack("<IHHHH", 12, ww, hh, 1, bpp)
+        else:
+            info = struct.pack("<IiiHHIIiiII", hsz, ww, -hh if top_down else hh, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+            if hsz >= 108:
+                info += masks + b"\0" * (hsz - 40 - len(masks))
+                masks = b""
+        off = 14 + len(info) + len(masks) + len(palette)
+        raw_file(name, b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + info + masks + palette + body)
+    bgr_rows = [row[:, ::-1].tobytes() for row in a]
+    bmp("topdown24.bmp", 40, 24, bgr_rows, top_down=True)
+    bmp("os2_24.bmp", 12, 24, bgr_rows)
+    bmp("os2_pal8.bmp", 12, 8, [row.tobytes() for row in idx], palette=pal[:, ::-1].tobytes())
+    idx16 = (idx % 16).astype(np.uint8)
+    packed4 = [bytes(((int(r[i]) << 4) | (int(r[i + 1]) if i + 1 < len(r) else 0)) for i in range(0, len(r), 2)) for r in idx16]
+    bmp("pal4.bmp", 40, 4, packed4, palette=b"".join(bytes([int(c[2]), int(c[1]), int(c[0]), 0]) for c in pal[:16]))
+    v555 = ((a[:, :, 0].astype(np.uint16) >> 3) << 10) | ((a[:, :, 1].astype(np.uint16) >> 3) << 5) | (a[:, :, 2].astype(np.uint16) >> 3)
+    bmp("rgb555.bmp", 40, 16, [row.astype("<u2").tobytes() for row in v555])
+    v565 = ((a[:, :, 0].astype(np.uint16) >> 3) << 11) | ((a[:, :, 1].astype(np.uint16) >> 2) << 5) | (a[:, :, 2].astype(np.uint16) >> 3)
+    bmp("rgb565_bitfields.bmp", 40, 16, [row.astype("<u2").tobytes() for row in v565], compress=3, masks=struct.pack("<III", 0xf800, 0x07e0, 0x001f))
+    x32 = (a[:, :, 0].astype(np.uint32) << 16) | (a[:, :, 1].astype(np.uint32) << 8) | a[:, :, 2].astype(np.uint32)
+    bmp("xrgb32_alpha_all_zero.bmp", 40, 32, [row.astype("<u4").tobytes() for row in x32])
+    odd = ((a[:, :, 0].astype(np.uint32) >> 2) << 20) | ((a[:, :, 1].astype(np.uint32) >> 1) << 9) | ((a[:, :, 2].astype(np.uint32) >> 5) << 2) | ((a[:, :, 1].astype(np.uint32) >> 4) << 28)
+    bmp("odd_masks_v4.bmp", 108, 32, [row.astype("<u4").tobytes() for row in odd], compress=3, masks=struct.pack("<IIII", 63 << 20, 127 << 9, 7 << 2, 15 << 28))
+    save("rgb.tga", a)
+    save("rgba_rle.tga", rgba, compression="tga_rle")
+    save("grey.tga", a, mode="L")
+    save("grey_rle.tga", (a[:, :, 0] // 64 * 64), compression="tga_rle")
+    save("palette.tga", a, mode="P")
+    save("palette_rle.tga", (a // 96 * 96), mode="P", compression="tga_rle")
+    save("rgb_topdown.tga", a, orientation=1)
+
+    def tga(name, kind, bits, body, descriptor=0, cmap=b"", cmap_len=0, cmap_bits=0, ident=b""):
+        raw_file(name, struct.pack("<BBBHHBHHHHBB", len(ident), 1 if cmap else 0, kind, 0, cmap_len, cmap_bits, 0, 0, a.shape[1], a.shape[0], bits, descriptor) + ident + cmap + body)
+    tga("rgb555.tga", 2, 16, (v555 | 0x8000).astype("<u2").tobytes(), ident=b"five bits a channel")
+    tga("grey_alpha16.tga", 3, 16, np.stack([grey, a[:, :, 2]], -1).tobytes(), descriptor=0x28)
+    tga("palette_of_555.tga", 1, 8, (idx % 32).astype(np.uint8).tobytes(), cmap=v555[0, :32].astype("<u2").tobytes(), cmap_len=32, cmap_bits=16)
+    save("palette.gif", a)
+    save("interlaced.gif", a, interlace=True)
+    save("sequential.gif", a, interlace=False)
+    save("grey.gif", a, mode="L")
+    Image.fromarray(a).convert("P").save(os.path.join(tmp, "transparent.gif"), transparency=5)
+    out.append(("transparent.gif", os.path.join(tmp, "transparent.gif")))
+    save("big_lzw.gif", field(200, 120))
+    # a frame smaller than the screen, with a background index: the uncovered border takes the background entry
+    small = Image.fromarray(a).convert("P")
+    p = os.path.join(tmp, "frame_inside_screen.gif")
+    small.save(p)
+    raw = bytearray(open(p, "rb").read())
+    assert raw[6:10] == struct.pack("<HH", a.shape[1], a.shape[0])
+    raw[6:10] = struct.pack("<HH", a.shape[1] + 6, a.shape[0] + 5)
+    raw[11] = 7                                                        # background colour index
+    at = raw.index(b"\x2c" + struct.pack("<HHHH", 0, 0, a.shape[1], a.shape[0]))
+    raw[at + 1:at + 5] = struct.pack("<HH", 4, 2)
+    open(p, "wb").write(bytes(raw))
+    out.append(("frame_inside_screen.gif", p))
+    raw_file("grey.pgm", b"P5\n# a comment\n%d %d\n255\n" % (a.shape[1], a.shape[0]) + grey.tobytes())
+    raw_file("rgb.ppm", b"P6 %d %d 255\n" % (a.shape[1], a.shape[0]) + a.tobytes())
+    raw_file("rgb_max100.ppm", b"P6\n%d\n%d\n100\n" % (a.shape[1], a.shape[0]) + (a // 3).astype(np.uint8).tobytes())
+    raw_file("rgb16.ppm", b"P6 %d %d 65535 " % (a.shape[1], a.shape[0]) + np.stack([a, a[:, :, ::-1]], -1).tobytes())
     return out
 
 

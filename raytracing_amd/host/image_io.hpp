@@ -1,13 +1,16 @@
 // raytracing_amd/host/image_io.hpp -- image read/write for the host driver.
 // The reference uses the vendored stb_image / stb_image_write (texture.hpp:87, raytracing.cpp:124-125); those are
-// third-party sources this repository does not carry, so the two calls the renderer needs are provided here: PNG decode on
-// top of zlib (every colour type and bit depth, Adam7 included), JPEG decode (jpeg_decode.hpp: baseline and progressive), binary PPM
-// decode, and PNG encode.  Decoded texels use stb's layout: rows top to bottom, channels interleaved, as many channels as the
-// file holds (the `0` of stbi_load(path, &w, &h, &ch, 0)).
+// third-party sources this repository does not carry, so the two calls the renderer needs are provided here: decoders for PNG
+// (on zlib; every colour type and bit depth, Adam7 included), BMP, GIF (first frame), JPEG (jpeg_decode.hpp: baseline and
+// progressive), binary PGM / PPM and TGA, and a PNG encoder.  Decoded texels are the ones stb_image hands the reference -- rows top
+// to bottom, channels interleaved, as many channels as stb reports for the file (the `0` of stbi_load(path, &w, &h, &ch, 0)),
+// its conversions and quirks included; tests/golden/images.npz holds the reference loader's output for 76 files and the host
+// tests compare byte for byte.  Not read: PSD, PIC, HDR.
 #pragma once
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -152,31 +155,349 @@ inline bool rt_decode_png(const std::vector<unsigned char>& file, std::vector<un
     return true;
 }
 
+// Binary PGM / PPM (P5 / P6) as stb reads them: the samples as stored (a maximum below 255 does not rescale them); of a two-byte
+// sample (maximum above 255) the SECOND byte survives -- stb loads the big-endian pairs as host (little-endian) words before it
+// takes their high byte, and the fixture pins that.
 inline bool rt_decode_ppm(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
 {
-    if (file.size() < 11 || file[0] != 'P' || file[1] != '6') return false;
+    if (file.size() < 8 || file[0] != 'P' || (file[1] != '5' && file[1] != '6')) return false;
     size_t pos = 2;
     int vals[3], got = 0;
     while (got < 3 && pos < file.size()) {
-        while (pos < file.size() && (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t')) pos++;
-        if (pos < file.size() && file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; continue; }
+        while (pos < file.size() && (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t' || file[pos] == '\v' || file[pos] == '\f')) pos++;
+        if (pos < file.size() && file[pos] == '#') { while (pos < file.size() && file[pos] != '\n' && file[pos] != '\r') pos++; continue; }
         int v = 0; bool any = false;
         while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') { if (v < (1 << 24)) v = v * 10 + (file[pos] - '0'); pos++; any = true; }
         if (!any) return false;
         vals[got++] = v;
     }
     pos++;
-    w = vals[0]; h = vals[1]; ch = 3;
-    if (got < 3 || vals[2] != 255 || w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28) || pos + (size_t) w * h * 3 > file.size()) return false;
-    pixels.assign(file.begin() + pos, file.begin() + pos + (size_t) w * h * 3);
+    if (got < 3) return false;
+    w = vals[0]; h = vals[1]; ch = file[1] == '6' ? 3 : 1;
+    int bytes = vals[2] > 255 ? 2 : 1;
+    if (vals[2] < 1 || vals[2] > 65535 || w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28)) return false;
+    size_t n = (size_t) w * h * ch;
+    if (pos + n * bytes > file.size()) return false;
+    pixels.resize(n);
+    for (size_t i = 0; i < n; i++) pixels[i] = file[pos + i * bytes + (bytes - 1)];
     return true;
+}
+
+// little-endian fields of BMP and TGA headers; reads past the end give 0, as stb's do
+struct rt_le_reader {
+    const std::vector<unsigned char>& f;
+    size_t pos = 0;
+    explicit rt_le_reader(const std::vector<unsigned char>& file) : f(file) {}
+    int u8() { return pos < f.size() ? f[pos++] : (pos++, 0); }
+    int u16() { int lo = u8(); return lo | (u8() << 8); }
+    uint32_t u32() { uint32_t lo = (uint32_t) u16(); return lo | ((uint32_t) u16() << 16); }
+    void skip(long long n) { if (n > 0) pos += (size_t) n; }
+};
+
+// Windows / OS/2 bitmaps as stb reads them: 1 / 4 / 8-bit palettes, 16 / 24 / 32-bit pixels with the default or BI_BITFIELDS masks
+// (a channel of n < 8 bits is widened by bit replication), bottom-up or top-down rows; no RLE.  Three channels, or four when the
+// file has an alpha mask (an alpha plane that is zero everywhere reads as opaque).
+inline bool rt_decode_bmp(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    if (file.size() < 26 || file[0] != 'B' || file[1] != 'M') return false;
+    rt_le_reader r(file);
+    r.skip(10);
+    long long offset = (int32_t) r.u32();
+    int hsz = (int) r.u32(), extra = 14;
+    if (offset < 0 || (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124)) return false;
+    long long iw, ih;
+    if (hsz == 12) { iw = r.u16(); ih = r.u16(); } else { iw = (int32_t) r.u32(); ih = (int32_t) r.u32(); }
+    if (r.u16() != 1) return false;
+    int bpp = r.u16(), compress = 0;
+    uint32_t mr = 0, mg = 0, mb = 0, ma = 0;
+    bool alpha_seen = true;                      // only the default 32-bit layout starts from "no alpha seen yet"
+    auto default_masks = [&]() {
+        if (bpp == 16) { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+        else if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; alpha_seen = false; }
+        else mr = mg = mb = ma = 0;
+    };
+    if (hsz != 12) {
+        compress = (int) r.u32();
+        if (compress == 1 || compress == 2 || compress >= 4 || compress < 0) return false;
+        if (compress == 3 && bpp != 16 && bpp != 32) return false;
+        r.skip(20);
+        if (hsz == 40 || hsz == 56) {
+            if (hsz == 56) r.skip(16);
+            if (bpp == 16 || bpp == 32) {
+                if (compress == 0) default_masks();
+                else { mr = r.u32(); mg = r.u32(); mb = r.u32(); extra += 12; if (mr == mg && mg == mb) return false; }
+            }
+        }
+        else {
+            mr = r.u32(); mg = r.u32(); mb = r.u32(); ma = r.u32();
+            if (compress != 3) default_masks();
+            r.skip(hsz == 124 ? 68 : 52);
+        }
+    }
+    bool bottom_up = ih > 0;
+    if (ih < 0) ih = -ih;
+    if (iw <= 0 || ih <= 0 || iw > (1 << 24) || ih > (1 << 24) || (uint64_t) iw * ih > (1ull << 28)) return false;
+    w = (int) iw; h = (int) ih;
+    if ((uint64_t) w * h * (uint64_t) bpp / 8 > (uint64_t) file.size()) return false;   // the pixels have to be in the file
+    int psize = 0;
+    if (hsz == 12) { if (bpp < 24) psize = (int) ((offset - extra - 24) / 3); }
+    else if (bpp < 16) psize = (int) ((offset - extra - hsz) >> 2);
+    if (psize == 0 && offset != (long long) r.pos) return false;
+    ch = (bpp == 24 && ma == 0xff000000u) ? 3 : (ma ? 4 : 3);
+    pixels.assign((size_t) w * h * ch, 0);
+    size_t z = 0;
+    if (bpp < 16) {
+        if (psize <= 0 || psize > 256 || (bpp != 1 && bpp != 4 && bpp != 8)) return false;
+        unsigned char pal[256][3] = { { 0 } };
+        for (int i = 0; i < psize; i++) { pal[i][2] = (unsigned char) r.u8(); pal[i][1] = (unsigned char) r.u8(); pal[i][0] = (unsigned char) r.u8(); if (hsz != 12) r.u8(); }
+        r.skip(offset - extra - hsz - (long long) psize * (hsz == 12 ? 3 : 4));
+        int row_bytes = bpp == 1 ? (w + 7) >> 3 : bpp == 4 ? (w + 1) >> 1 : w, pad = (-row_bytes) & 3;
+        for (int j = 0; j < h; j++) {
+            size_t row_at = r.pos;
+            for (int i = 0; i < w; i++) {
+                size_t bit = (size_t) i * bpp;
+                size_t at = row_at + (bit >> 3);
+                int v = at < file.size() ? file[at] : 0;
+                int index = (v >> (8 - bpp - (int) (bit & 7))) & ((1 << bpp) - 1);
+                for (int c = 0; c < 3; c++) pixels[z++] = pal[index][c];
+                if (ch == 4) pixels[z++] = 255;
+            }
+            r.pos = row_at + row_bytes + pad;
+        }
+    }
+    else {
+        if (bpp != 16 && bpp != 24 && bpp != 32) return false;
+        r.skip(offset - extra - hsz);
+        int pad = bpp == 24 ? (-3 * w) & 3 : bpp == 16 ? (-2 * w) & 3 : 0;
+        bool plain = bpp == 24 || (bpp == 32 && mb == 0xff && mg == 0xff00 && mr == 0x00ff0000 && ma == 0xff000000u);
+        auto top_bit = [](uint32_t m) { int n = -1; while (m) { n++; m >>= 1; } return n; };
+        auto count = [](uint32_t m) { int n = 0; while (m) { n += m & 1; m >>= 1; } return n; };
+        auto widen = [](uint32_t v, int shift, int bits) {       // the field's top bit to bit 7, then the n-bit value replicated to 8
+            static const unsigned mul[9] = { 0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01 }, down[9] = { 0, 0, 0, 1, 0, 2, 4, 6, 0 };
+            v = shift < 0 ? v << -shift : v >> shift;
+            v >>= (8 - bits);
+            return (int) ((v * mul[bits]) >> down[bits]);
+        };
+        int rs = 0, gs = 0, bs = 0, as = 0, rc = 0, gc = 0, bc = 0, ac = 0;
+        if (!plain) {
+            if (!mr || !mg || !mb) return false;
+            rs = top_bit(mr) - 7; gs = top_bit(mg) - 7; bs = top_bit(mb) - 7; as = top_bit(ma) - 7;
+            rc = count(mr); gc = count(mg); bc = count(mb); ac = count(ma);
+            if (rc > 8 || gc > 8 || bc > 8 || ac > 8) return false;
+        }
+        unsigned all_alpha = alpha_seen ? 255 : 0;
+        for (int j = 0; j < h; j++) {
+            for (int i = 0; i < w; i++) {
+                unsigned alpha;
+                if (plain) {
+                    pixels[z + 2] = (unsigned char) r.u8(); pixels[z + 1] = (unsigned char) r.u8(); pixels[z] = (unsigned char) r.u8();
+                    z += 3;
+                    alpha = bpp == 32 ? (unsigned) r.u8() : 255;
+                }
+                else {
+                    uint32_t v = bpp == 16 ? (uint32_t) r.u16() : r.u32();
+                    pixels[z++] = (unsigned char) widen(v & mr, rs, rc);
+                    pixels[z++] = (unsigned char) widen(v & mg, gs, gc);
+                    pixels[z++] = (unsigned char) widen(v & mb, bs, bc);
+                    alpha = ma ? (unsigned) widen(v & ma, as, ac) : 255;
+                }
+                all_alpha |= alpha;
+                if (ch == 4) pixels[z++] = (unsigned char) alpha;
+            }
+            r.skip(pad);
+        }
+        if (ch == 4 && all_alpha == 0) for (size_t i = 3; i < pixels.size(); i += 4) pixels[i] = 255;
+    }
+    if (bottom_up) {
+        size_t stride = (size_t) w * ch;
+        for (int j = 0; j < h / 2; j++) std::swap_ranges(&pixels[stride * j], &pixels[stride * j] + stride, &pixels[stride * (h - 1 - j)]);
+    }
+    return true;
+}
+
+// Truevision TGA as stb reads it: true-colour 15 / 16 / 24 / 32 bits, grey 8 / 16 bits, colour-mapped with 8 or 16-bit indices, each
+// raw or run-length packed, either row order; 15 / 16-bit colours become RGB through x*255/31 with the top bit ignored.  The format
+// has no signature, so this reader comes last and checks the header fields stb checks.
+inline bool rt_decode_tga(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    if (file.size() < 18) return false;
+    rt_le_reader r(file);
+    int id_len = r.u8(), mapped = r.u8(), kind = r.u8();
+    int map_first = r.u16(), map_len = r.u16(), map_bits = r.u8();
+    r.skip(4);
+    w = r.u16(); h = r.u16();
+    int bits = r.u8(), descriptor = r.u8();
+    if (mapped > 1 || w < 1 || h < 1) return false;
+    if ((uint64_t) w * h > (uint64_t) file.size() * 128) return false;       // a run packs at most 128 pixels into two bytes
+    if (mapped) { if ((kind != 1 && kind != 9) || (bits != 8 && bits != 16)) return false; }
+    else if (kind != 2 && kind != 3 && kind != 10 && kind != 11) return false;
+    bool packed = kind >= 8, grey = (kind & 7) == 3, top_down = (descriptor >> 5) & 1;
+    int depth = mapped ? map_bits : bits;
+    bool rgb16 = depth == 15 || (depth == 16 && !(grey && !mapped));
+    ch = depth == 8 ? 1 : (depth == 16 && grey && !mapped) ? 2 : rgb16 ? 3 : (depth == 24 || depth == 32) ? depth / 8 : 0;
+    if (!ch) return false;
+    r.skip(id_len);
+    auto read_px = [&](unsigned char* out, bool as16) {
+        if (as16) { int px = r.u16(); out[0] = (unsigned char) ((((px >> 10) & 31) * 255) / 31); out[1] = (unsigned char) ((((px >> 5) & 31) * 255) / 31); out[2] = (unsigned char) (((px & 31) * 255) / 31); }
+        else for (int c = 0; c < ch; c++) out[c] = (unsigned char) r.u8();
+    };
+    std::vector<unsigned char> palette;
+    if (mapped) {
+        if (map_len == 0) return false;
+        r.skip(map_first);
+        palette.resize((size_t) map_len * ch);
+        if (!rgb16 && r.pos + palette.size() > file.size()) return false;
+        for (int i = 0; i < map_len; i++) read_px(&palette[(size_t) i * ch], rgb16);
+    }
+    size_t n_px = (size_t) w * h;
+    pixels.assign(n_px * ch, 0);
+    unsigned char px[4] = { 0, 0, 0, 0 };
+    int run = 0;
+    bool repeating = false;
+    for (size_t i = 0; i < n_px; i++) {
+        bool fetch = true;
+        if (packed) {
+            if (run == 0) { int cmd = r.u8(); run = 1 + (cmd & 127); repeating = cmd >> 7; }
+            else if (repeating) fetch = false;
+        }
+        if (fetch) {
+            if (mapped) {
+                int index = bits == 8 ? r.u8() : r.u16();
+                if (index >= map_len) index = 0;
+                for (int c = 0; c < ch; c++) px[c] = palette[(size_t) index * ch + c];
+            }
+            else read_px(px, rgb16);
+        }
+        for (int c = 0; c < ch; c++) pixels[i * ch + c] = px[c];
+        run--;
+    }
+    if (!top_down) {
+        size_t stride = (size_t) w * ch;
+        for (int j = 0; j * 2 < h; j++) if (j != h - 1 - j) std::swap_ranges(&pixels[stride * j], &pixels[stride * j] + stride, &pixels[stride * (h - 1 - j)]);
+    }
+    if (ch >= 3 && !rgb16) for (size_t i = 0; i < n_px; i++) std::swap(pixels[i * ch], pixels[i * ch + 2]);     // stored blue first
+    return true;
+}
+
+// GIF as stb reads it for a still picture: the first frame only, always four channels.  Pixels of the transparent index and pixels
+// the frame does not cover stay (0,0,0,0) -- unless the header names a background index above 0, in which case the uncovered ones
+// take that palette entry, opaque, and with red and blue exchanged (stb copies its blue-first palette entry as it lies; the
+// fixture pins it).  LZW per the GIF89a specification, interlaced frames included.
+inline bool rt_decode_gif(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    if (file.size() < 13 || std::memcmp(file.data(), "GIF8", 4) != 0 || (file[4] != '7' && file[4] != '9') || file[5] != 'a') return false;
+    rt_le_reader r(file);
+    r.skip(6);
+    w = r.u16(); h = r.u16();
+    int flags = r.u8(), background = r.u8();
+    r.u8();
+    if (w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28)) return false;
+    struct entry { unsigned char r, g, b, a; };
+    std::vector<entry> global(256, entry{ 0, 0, 0, 0 }), local(256, entry{ 0, 0, 0, 0 });
+    auto read_table = [&](std::vector<entry>& t, int n, int transparent) {
+        for (int i = 0; i < n; i++) { t[i].r = (unsigned char) r.u8(); t[i].g = (unsigned char) r.u8(); t[i].b = (unsigned char) r.u8(); t[i].a = i == transparent ? 0 : 255; }
+    };
+    if (flags & 0x80) read_table(global, 2 << (flags & 7), -1);
+    int transparent = -1, control = 0;
+    ch = 4;
+    for (;;) {
+        if (r.pos >= file.size()) return false;
+        int tag = r.u8();
+        if (tag == 0x21) {
+            int kind = r.u8();
+            if (kind == 0xf9) {
+                int len = r.u8();
+                if (len != 4) { r.skip(len); continue; }
+                control = r.u8();
+                r.u16();
+                if (transparent >= 0) global[transparent].a = 255;
+                if (control & 1) { transparent = r.u8(); global[transparent].a = 0; }
+                else { r.u8(); transparent = -1; }
+            }
+            for (int len = r.u8(); len != 0; len = r.u8()) r.skip(len);
+            continue;
+        }
+        if (tag != 0x2c) return false;               // a trailer before any image, or an unknown block
+        int fx = r.u16(), fy = r.u16(), fw = r.u16(), fh = r.u16();
+        if (fx + fw > w || fy + fh > h) return false;
+        int lflags = r.u8();
+        const std::vector<entry>* table;
+        if (lflags & 0x80) { read_table(local, 2 << (lflags & 7), (control & 1) ? transparent : -1); table = &local; }
+        else if (flags & 0x80) table = &global;
+        else return false;
+        pixels.assign((size_t) w * h * 4, 0);
+        std::vector<unsigned char> touched((size_t) w * h, 0);
+        // raster position: rows go 0, 8, 16, ... then 4, 12, ... then 2, 6, ... then 1, 3, ... when the frame is interlaced
+        int x = fx, y = fy, step = (lflags & 0x40) ? 8 : 1, passes_left = (lflags & 0x40) ? 3 : 0;
+        if (fw == 0) y = fy + fh;
+        auto put = [&](int index) {
+            if (y >= fy + fh) return;
+            size_t at = (size_t) y * w + x;
+            touched[at] = 1;
+            const entry& e = (*table)[index];
+            if (e.a > 128) { pixels[at * 4] = e.r; pixels[at * 4 + 1] = e.g; pixels[at * 4 + 2] = e.b; pixels[at * 4 + 3] = e.a; }
+            if (++x >= fx + fw) {
+                x = fx;
+                y += step;
+                while (y >= fy + fh && passes_left > 0) { step = 1 << passes_left; y = fy + (step >> 1); passes_left--; }
+            }
+        };
+        int min_size = r.u8();
+        if (min_size > 12) return false;
+        const int clear = 1 << min_size;
+        std::vector<int16_t> prefix(8192, -1);
+        std::vector<unsigned char> head(8192, 0), tail(8192, 0), chain(8192);
+        for (int i = 0; i < clear; i++) head[i] = tail[i] = (unsigned char) i;
+        int width = min_size + 1, mask = (1 << width) - 1, next = clear + 2, previous = -1, in_block = 0;
+        uint32_t acc = 0;
+        int have = 0;
+        bool cleared = false, done = false;
+        while (!done) {
+            if (have < width) {
+                if (in_block == 0) { in_block = r.u8(); if (in_block == 0) break; }
+                in_block--;
+                acc |= (uint32_t) r.u8() << have;
+                have += 8;
+                continue;
+            }
+            int code = (int) (acc & (uint32_t) mask);
+            acc >>= width; have -= width;
+            if (code == clear) { width = min_size + 1; mask = (1 << width) - 1; next = clear + 2; previous = -1; cleared = true; }
+            else if (code == clear + 1) done = true;
+            else if (code <= next) {
+                if (!cleared) return false;
+                if (previous >= 0) {
+                    if (next >= 8192) return false;
+                    prefix[next] = (int16_t) previous;
+                    head[next] = head[previous];
+                    tail[next] = code == next ? head[next] : head[code];
+                    next++;
+                }
+                else if (code == next) return false;
+                int n = 0;
+                for (int c = code; c >= 0 && n < 8192; c = prefix[c]) chain[n++] = tail[c];
+                while (n > 0) put(chain[--n]);
+                if ((next & mask) == 0 && next <= 0x0fff) { width++; mask = (1 << width) - 1; }
+                previous = code;
+            }
+            else return false;
+        }
+        if (background > 0) {
+            entry e = global[background];
+            for (size_t i = 0; i < touched.size(); i++)
+                if (!touched[i]) { pixels[i * 4] = e.b; pixels[i * 4 + 1] = e.g; pixels[i * 4 + 2] = e.r; pixels[i * 4 + 3] = 255; }
+        }
+        return true;
+    }
 }
 
 inline bool rt_load_image(const char* path, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
 {
     std::vector<unsigned char> file;
     if (!rt_read_file(path, file)) return false;
-    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_jpeg(file, pixels, w, h, ch) || rt_decode_ppm(file, pixels, w, h, ch);   // stb tries them in this order
+    // stb's order of trying (of the formats read here): PNG, BMP, GIF, JPEG, PNM, and TGA last, which has no signature
+    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_bmp(file, pixels, w, h, ch) || rt_decode_gif(file, pixels, w, h, ch) || rt_decode_jpeg(file, pixels, w, h, ch) ||
+           rt_decode_ppm(file, pixels, w, h, ch) || rt_decode_tga(file, pixels, w, h, ch);
 }
 
 // 8-bit RGB/RGBA/gray PNG.  flip_vertically mirrors stbi_flip_vertically_on_write(true) (raytracing.cpp:124): the
