@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ private:
     std::string scene_path;
     std::vector<material*> mats;
     std::map<std::string, int> mat_index;
+    std::set<std::string> loaded_mtl;
     std::vector<float> pos, nrm, tex;
 
     static std::string dirname(const std::string& p)
@@ -57,10 +59,36 @@ private:
     }
     static float to_float(const std::string& s) { return (float) std::strtod(s.c_str(), nullptr); }
 
-    void load_mtl(const std::string& file)
+    // `map_Kd [options] file name`, the way tinyobjloader reads it (ParseTextureNameAndOption, tiny_obj_loader.hpp:1247-1331): options
+    // in front of the name are skipped with the number of arguments tinyobj consumes for each (three for -o / -s / -t, two for -mm, one
+    // for the others, whatever the tokens are), and the name is the REST of the line, blanks included.
+    static std::string texture_name(std::istringstream& ss)
+    {
+        std::string tok;
+        while (ss >> tok) {
+            int skip = -1;
+            if (tok == "-o" || tok == "-s" || tok == "-t") skip = 3;
+            else if (tok == "-mm") skip = 2;
+            else if (tok == "-blendu" || tok == "-blendv" || tok == "-clamp" || tok == "-boost" || tok == "-bm" || tok == "-type" || tok == "-texres" ||
+                     tok == "-imfchan" || tok == "-colorspace") skip = 1;
+            if (skip < 0) {
+                std::string rest;
+                std::getline(ss, rest);
+                tok += rest;
+                while (!tok.empty() && (tok.back() == '\r' || tok.back() == ' ' || tok.back() == '\t')) tok.pop_back();
+                return tok;
+            }
+            std::string arg;
+            for (int k = 0; k < skip; k++) ss >> arg;
+        }
+        return std::string();
+    }
+
+    // one MTL file; false when it cannot be opened
+    bool load_mtl(const std::string& file)
     {
         std::ifstream in(dirname(scene_path) + "/" + file);
-        if (!in) { std::printf("[OBJLoader] warning: material file %s not found\n", file.c_str()); return; }
+        if (!in) return false;
         phong* cur = nullptr;
         std::string line;
         while (std::getline(in, line)) {
@@ -84,12 +112,34 @@ private:
             else if (key == "Ns") { std::string a; ss >> a; cur->Ns = to_float(a); }
             else if (key == "Ni") { std::string a; ss >> a; cur->Ni = to_float(a); }
             else if (key == "map_Kd") {
-                std::string name; ss >> name;
+                std::string name = texture_name(ss);
+                if (name.empty()) continue;
                 std::string image_path = dirname(scene_path) + "/" + name;
                 std::printf("[OBJLoader] load diffuse image: %s\n", image_path.c_str());
                 cur->diffuse_map = new image(image_path.c_str(), true);
             }
         }
+        return true;
+    }
+
+    // `mtllib a.mtl b.mtl`: names separated by blanks (a backslash keeps the next character), tried in turn until one loads; a file
+    // that has been loaded before is not read again (tiny_obj_loader.hpp:2843-2893)
+    void load_mtllib(const std::string& rest)
+    {
+        std::vector<std::string> names(1);
+        for (size_t i = 0; i < rest.size(); i++) {
+            char c = rest[i];
+            if (c == '\\' && i + 1 < rest.size()) names.back() += rest[++i];
+            else if (c == ' ') { if (!names.back().empty()) names.emplace_back(); }
+            else if (c != '\r' && c != '\t') names.back() += c;
+        }
+        if (names.back().empty()) names.pop_back();
+        bool found = false;
+        for (const std::string& n : names) {
+            if (loaded_mtl.count(n)) { found = true; continue; }
+            if (load_mtl(n)) { loaded_mtl.insert(n); found = true; break; }
+        }
+        if (!found) std::printf("[OBJLoader] warning: failed to load material file(s): %s\n", rest.c_str());
     }
 
     // Polygons with more than four corners, the way tinyobjloader 2.0.0's built-in triangulation cuts them (tiny_obj_loader.hpp:1715-1936;
@@ -165,7 +215,7 @@ private:
             if (key == "v") { std::string a, b, c; ss >> a >> b >> c; pos.push_back(to_float(a)); pos.push_back(to_float(b)); pos.push_back(to_float(c)); }
             else if (key == "vn") { std::string a, b, c; ss >> a >> b >> c; nrm.push_back(to_float(a)); nrm.push_back(to_float(b)); nrm.push_back(to_float(c)); }
             else if (key == "vt") { std::string a, b; ss >> a >> b; tex.push_back(to_float(a)); tex.push_back(to_float(b)); }
-            else if (key == "mtllib") { std::string f; ss >> f; load_mtl(f); }
+            else if (key == "mtllib") { std::string rest; std::getline(ss, rest); size_t b = rest.find_first_not_of(" \t"); load_mtllib(b == std::string::npos ? std::string() : rest.substr(b)); }
             else if (key == "usemtl") { std::string n; ss >> n; auto it = mat_index.find(n); cur_mat = it == mat_index.end() ? -1 : it->second; }
             else if (key == "f") {
                 std::vector<corner> face;

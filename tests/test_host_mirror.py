@@ -217,6 +217,26 @@ def test_jpeg_map_kd_reaches_the_scene_through_the_obj_loader(golden_dir, tmp_pa
     hs.free()
 
 
+def test_mtl_texture_options_and_material_library_lists(golden_dir, tmp_path):
+    """What tinyobjloader accepts and the reference therefore loads (tiny_obj_loader.hpp:1247-1331, 2843-2893): `map_Kd` with options in
+    front of the file name (each skipped with the number of arguments tinyobj consumes), a file name with a blank in it, CR-LF line
+    ends, and `mtllib` with several names of which the first that opens is used (a backslash keeps a blank inside a name)."""
+    g, names = _image_fixture(golden_dir)
+    k = names.index("rgb420_q75.jpg")
+    g["file%d" % k].tofile(str(tmp_path / "my tex.jpg"))
+    (tmp_path / "my mats.mtl").write_bytes(b"newmtl a\r\nKd 0.5 0.5 0.5\r\nmap_Kd -s 2 2 1 -bm 0.3 -clamp on -mm 0 1 my tex.jpg\r\n\r\nnewmtl l\r\nKe 4 4 4\r\n")
+    (tmp_path / "s.obj").write_bytes(b"mtllib missing.mtl my\\ mats.mtl unused.mtl\r\nv 0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nv 0 0 1\r\nvt 0 0\r\nvt 1 0\r\nvt 0 1\r\n"
+                                     b"usemtl a\r\nf 1/1 2/2 3/3\r\nusemtl l\r\nf 1/1 3/2 4/3\r\n")
+    hs = HostScene.obj(str(tmp_path / "s.obj"), 16, 16, 1)
+    d = hs.arrays()
+    assert int(hs.desc.contents.n_prims) == 2 and int(hs.desc.contents.n_lights) == 1
+    ti = int(d["mat_tex"][int(d["prim_mat"][0])])
+    w, h, ch, _ = [int(v) for v in g["dims%d" % k]]
+    assert ti >= 0 and [int(x) for x in d["tex_data"][ti][:3]] == [w, h, ch]
+    assert np.array_equal(d["tex_pixels"][int(d["tex_data"][ti][4]):][:w * h * ch], g["pixels%d" % k])
+    hs.free()
+
+
 def test_obj_loader_drops_faces_with_indices_outside_the_arrays(tmp_path):
     """A malformed or truncated OBJ (index 0, an index past the arrays, a relative index before their start) must not read outside the
     vertex arrays: such faces are dropped (tinyobj fails the parse on them), the good ones load, and a file with no usable face is
