@@ -396,6 +396,94 @@ def image_files(tmp):
     raw[at + 1:at + 5] = struct.pack("<HH", 4, 2)
     open(p, "wb").write(bytes(raw))
     out.append(("frame_inside_screen.gif", p))
+    # Radiance .hdr, Photoshop .psd, Softimage .pic: written by hand (Pillow writes none of them)
+    hh, ww = a.shape[:2]
+    expo = (120 + (np.arange(hh)[:, None] * 3 + np.arange(ww)[None, :]) % 14).astype(np.uint8)      # 2^-16 .. 2^-3 times the mantissa: dark to beyond white
+    expo[3, 5] = 0                                                                                    # the black pixel
+    rgbe = np.concatenate([np.maximum(a, 1), expo[:, :, None]], -1)
+    hdr_head = b"#?RADIANCE\nEXPOSURE=1.0\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (hh, ww)
+
+    def hdr_rle_rows(px):
+        out_rows = b""
+        for row in px:
+            out_rows += bytes([2, 2, ww >> 8, ww & 255])
+            for k in range(4):
+                col, i = row[:, k], 0
+                while i < ww:
+                    run = 1
+                    while i + run < ww and run < 127 and col[i + run] == col[i]:
+                        run += 1
+                    if run >= 3:
+                        out_rows += bytes([128 + run, int(col[i])]); i += run
+                    else:
+                        n = min(ww - i, 5)
+                        out_rows += bytes([n]) + col[i:i + n].tobytes(); i += n
+        return out_rows
+    raw_file("rle.hdr", hdr_head + hdr_rle_rows(rgbe))
+    raw_file("flat_rows.hdr", hdr_head.replace(b"#?RADIANCE", b"#?RGBE") + rgbe.tobytes())            # rows that do not start 2 2: stb's flat fallback
+    raw_file("narrow.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X 5\n" % hh + rgbe[:, :5].tobytes())
+
+    def psd(name, planes, depth, compression):
+        head = b"8BPS" + struct.pack(">H6xHIIHH", 1, len(planes), hh, ww, depth, 3) + struct.pack(">III", 0, 0, 0) + struct.pack(">H", compression)
+        if not compression:
+            body = b"".join(pl.astype(">u2").tobytes() if depth == 16 else pl.astype(np.uint8).tobytes() for pl in planes)
+        else:
+            rows, counts = [], []
+            for pl in planes:
+                for row in pl.astype(np.uint8):
+                    enc, i = b"", 0
+                    while i < ww:
+                        run = 1
+                        while i + run < ww and run < 128 and row[i + run] == row[i]:
+                            run += 1
+                        if run >= 2:
+                            enc += bytes([257 - run, int(row[i])]); i += run
+                        else:
+                            n = min(ww - i, 7)
+                            enc += bytes([n - 1]) + row[i:i + n].tobytes(); i += n
+                    enc += b"\x80"                                              # a no-op byte between rows
+                    rows.append(enc); counts.append(len(enc))
+            body = b"".join(struct.pack(">H", c) for c in counts) + b"".join(rows)
+        raw_file(name, head + body)
+    alpha = ((np.arange(hh)[:, None] * 37 + np.arange(ww)[None, :] * 11) % 256).astype(np.uint8)
+    alpha[0, :4] = (0, 255, 1, 254)
+    psd("rgb8_raw.psd", [a[:, :, 0], a[:, :, 1], a[:, :, 2]], 8, 0)
+    psd("rgba8_rle.psd", [a[:, :, 0] // 32 * 32, a[:, :, 1], a[:, :, 2], alpha], 8, 1)
+    psd("rgba16_raw.psd", [a[:, :, 0].astype(np.uint16) * 257, a[:, :, 1].astype(np.uint16) * 256 + 7, a[:, :, 2].astype(np.uint16) * 256 + 255, alpha.astype(np.uint16) * 257], 16, 0)
+
+    def pic(name, packets):
+        head = bytes([0x53, 0x80, 0xf6, 0x34]) + struct.pack(">f", 3.7) + b"made by hand".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", ww, hh, 1.0, 3, 0)
+        table = b"".join(bytes([1 if k + 1 < len(packets) else 0, 8, kind, chan]) for k, (kind, chan, _) in enumerate(packets))
+        body = b""
+        for y in range(hh):
+            for kind, chan, data in packets:
+                row = data[y]                                     # (ww, n channels of this packet)
+                if kind == 0:
+                    body += row.tobytes()
+                elif kind == 1:
+                    i = 0
+                    while i < ww:
+                        run = 1
+                        while i + run < ww and run < 255 and (row[i + run] == row[i]).all():
+                            run += 1
+                        body += bytes([run]) + row[i].tobytes(); i += run
+                else:
+                    i = 0
+                    while i < ww:
+                        run = 1
+                        while i + run < ww and run < 300 and (row[i + run] == row[i]).all():
+                            run += 1
+                        if run >= 2:
+                            body += (bytes([127 + run]) if run <= 128 else bytes([128]) + struct.pack(">H", run)) + row[i].tobytes(); i += run
+                        else:
+                            n = min(ww - i, 4)
+                            body += bytes([n - 1]) + row[i:i + n].tobytes(); i += n
+        raw_file(name, head + table + body)
+    coarse = a // 64 * 64
+    pic("rgb_raw.pic", [(0, 0xe0, a)])
+    pic("rgb_pure_rle.pic", [(1, 0xe0, coarse)])
+    pic("rgba_mixed_rle.pic", [(2, 0xe0, coarse), (2, 0x10, (alpha // 128 * 200)[:, :, None].astype(np.uint8))])
+    pic("red_and_blue_only.pic", [(0, 0x80, a[:, :, :1]), (1, 0x20, coarse[:, :, 2:3])])
     raw_file("grey.pgm", b"P5\n# a comment\n%d %d\n255\n" % (a.shape[1], a.shape[0]) + grey.tobytes())
     raw_file("rgb.ppm", b"P6 %d %d 255\n" % (a.shape[1], a.shape[0]) + a.tobytes())
     raw_file("rgb_max100.ppm", b"P6\n%d\n%d\n100\n" % (a.shape[1], a.shape[0]) + (a // 3).astype(np.uint8).tobytes())

@@ -1,16 +1,17 @@
 // raytracing_amd/host/image_io.hpp -- image read/write for the host driver.
 // The reference uses the vendored stb_image / stb_image_write (texture.hpp:87, raytracing.cpp:124-125); those are
-// third-party sources this repository does not carry, so the two calls the renderer needs are provided here: decoders for PNG
-// (on zlib; every colour type and bit depth, Adam7 included), BMP, GIF (first frame), JPEG (jpeg_decode.hpp: baseline and
-// progressive), binary PGM / PPM and TGA, and a PNG encoder.  Decoded texels are the ones stb_image hands the reference -- rows top
+// third-party sources this repository does not carry, so the two calls the renderer needs are provided here: decoders for every
+// format stb_image loads -- PNG (on zlib; every colour type and bit depth, Adam7 included), BMP, GIF (first frame), PSD, PIC, JPEG
+// (jpeg_decode.hpp: baseline and progressive), binary PGM / PPM, Radiance HDR and TGA -- and a PNG encoder.  Decoded texels are the ones stb_image hands the reference -- rows top
 // to bottom, channels interleaved, as many channels as stb reports for the file (the `0` of stbi_load(path, &w, &h, &ch, 0)),
-// its conversions and quirks included; tests/golden/images.npz holds the reference loader's output for 76 files and the host
-// tests compare byte for byte.  Not read: PSD, PIC, HDR.
+// its conversions and quirks included; tests/golden/images.npz holds the reference loader's output for 86 files and the host
+// tests compare byte for byte.
 #pragma once
 
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -491,13 +492,222 @@ inline bool rt_decode_gif(const std::vector<unsigned char>& file, std::vector<un
     }
 }
 
+// big-endian fields (PSD, PIC); reads past the end give 0 and are remembered
+struct rt_be_reader {
+    const std::vector<unsigned char>& f;
+    size_t pos = 0;
+    explicit rt_be_reader(const std::vector<unsigned char>& file) : f(file) {}
+    bool at_end() const { return pos >= f.size(); }
+    int u8() { return pos < f.size() ? f[pos++] : (pos++, 0); }
+    int u16() { int hi = u8(); return (hi << 8) | u8(); }
+    uint32_t u32() { uint32_t hi = (uint32_t) u16(); return (hi << 16) | (uint32_t) u16(); }
+    void skip(uint32_t n) { pos += n; }
+};
+
+// Photoshop PSD as stb reads it: the flattened RGB picture of an 8- or 16-bit file (16-bit samples cut to the high byte), raw or
+// PackBits rows, always four channels (alpha 255 when the file has none); where alpha is neither 0 nor 255 the colour is "un-matted"
+// from white with stb's float arithmetic, its wrap-around on out-of-range results included (the fixture pins it).
+inline bool rt_decode_psd(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    if (file.size() < 26 || std::memcmp(file.data(), "8BPS", 4) != 0) return false;
+    rt_be_reader r(file);
+    r.skip(4);
+    if (r.u16() != 1) return false;
+    r.skip(6);
+    int channels = r.u16();
+    if (channels < 0 || channels > 16) return false;
+    uint32_t hh = r.u32(), ww = r.u32();
+    int depth = r.u16();
+    if ((depth != 8 && depth != 16) || r.u16() != 3) return false;          // RGB only
+    if (ww == 0 || hh == 0 || ww > (1u << 24) || hh > (1u << 24) || (uint64_t) ww * hh > (1ull << 28)) return false;
+    r.skip(r.u32()); r.skip(r.u32()); r.skip(r.u32());                       // mode data, image resources, layers
+    int compression = r.u16();
+    if (compression > 1 || r.pos > file.size()) return false;
+    w = (int) ww; h = (int) hh; ch = 4;
+    size_t n_px = (size_t) w * h;
+    pixels.assign(n_px * 4, 0);
+    if (compression) r.skip((uint32_t) h * channels * 2);                    // the rows' byte counts
+    for (int c = 0; c < 4; c++) {
+        unsigned char* p = &pixels[c];
+        if (c >= channels) { for (size_t i = 0; i < n_px; i++) p[i * 4] = c == 3 ? 255 : 0; continue; }
+        if (!compression) {
+            for (size_t i = 0; i < n_px; i++) p[i * 4] = (unsigned char) (depth == 16 ? r.u16() >> 8 : r.u8());
+            continue;
+        }
+        size_t done = 0;
+        while (done < n_px) {
+            int len = r.u8();
+            if (r.pos > file.size()) return false;
+            if (len == 128) continue;
+            if (len < 128) { len++; if ((size_t) len > n_px - done) return false; for (; len; len--) p[done++ * 4] = (unsigned char) r.u8(); }
+            else { len = 257 - len; if ((size_t) len > n_px - done) return false; unsigned char v = (unsigned char) r.u8(); for (; len; len--) p[done++ * 4] = v; }
+        }
+    }
+    if (channels >= 4)
+        for (size_t i = 0; i < n_px; i++) {
+            unsigned char* px = &pixels[i * 4];
+            if (px[3] != 0 && px[3] != 255) {
+                float a = px[3] / 255.0f, ra = 1.0f / a, inv_a = 255.0f * (1 - ra);
+                for (int c = 0; c < 3; c++) px[c] = (unsigned char) (int) (px[c] * ra + inv_a);
+            }
+        }
+    return true;
+}
+
+// Softimage PIC as stb reads it: 8-bit channel packets, each raw, run-length or mixed; three channels, four when a packet carries alpha
+// (a channel no packet carries stays 255).
+inline bool rt_decode_pic(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    static const unsigned char magic[4] = { 0x53, 0x80, 0xf6, 0x34 };
+    if (file.size() < 104 || std::memcmp(file.data(), magic, 4) != 0 || std::memcmp(&file[88], "PICT", 4) != 0) return false;
+    rt_be_reader r(file);
+    r.skip(92);
+    w = r.u16(); h = r.u16();
+    r.skip(8);                                            // ratio, fields, pad
+    if (w <= 0 || h <= 0) return false;
+    struct packet { int type, channel; } packets[10];
+    int n_packets = 0, carried = 0, chained;
+    do {
+        if (n_packets == 10) return false;
+        chained = r.u8();
+        int size = r.u8();
+        packets[n_packets].type = r.u8(); packets[n_packets].channel = r.u8();
+        carried |= packets[n_packets].channel;
+        n_packets++;
+        if (r.at_end() || size != 8) return false;
+    } while (chained);
+    std::vector<unsigned char> rgba((size_t) w * h * 4, 0xff);
+    auto read_value = [&](int channel, unsigned char* dest) {
+        for (int i = 0, mask = 0x80; i < 4; i++, mask >>= 1)
+            if (channel & mask) { if (r.at_end()) return false; dest[i] = (unsigned char) r.u8(); }
+        return true;
+    };
+    auto copy_value = [](int channel, unsigned char* dest, const unsigned char* src) { for (int i = 0, mask = 0x80; i < 4; i++, mask >>= 1) if (channel & mask) dest[i] = src[i]; };
+    for (int y = 0; y < h; y++)
+        for (int k = 0; k < n_packets; k++) {
+            unsigned char* dest = &rgba[(size_t) y * w * 4];
+            const int channel = packets[k].channel;
+            if (packets[k].type == 0) { for (int x = 0; x < w; x++, dest += 4) if (!read_value(channel, dest)) return false; }
+            else if (packets[k].type == 1) {
+                for (int left = w; left > 0;) {
+                    int count = r.u8();
+                    unsigned char value[4];
+                    if (r.at_end()) return false;
+                    if (count > left) count = left & 255;
+                    if (!read_value(channel, value)) return false;
+                    for (int i = 0; i < count; i++, dest += 4) copy_value(channel, dest, value);
+                    left -= count;
+                    if (count == 0) return false;      // a run of nothing would never end
+                }
+            }
+            else if (packets[k].type == 2) {
+                for (int left = w; left > 0;) {
+                    int count = r.u8();
+                    if (r.at_end()) return false;
+                    if (count >= 128) {
+                        unsigned char value[4];
+                        count = count == 128 ? r.u16() : count - 127;
+                        if (count > left || !read_value(channel, value)) return false;
+                        for (int i = 0; i < count; i++, dest += 4) copy_value(channel, dest, value);
+                    }
+                    else {
+                        count++;
+                        if (count > left) return false;
+                        for (int i = 0; i < count; i++, dest += 4) if (!read_value(channel, dest)) return false;
+                    }
+                    left -= count;
+                    if (count == 0) return false;
+                }
+            }
+            else return false;
+        }
+    ch = (carried & 0x10) ? 4 : 3;
+    pixels.resize((size_t) w * h * ch);
+    for (size_t i = 0; i < (size_t) w * h; i++) for (int c = 0; c < ch; c++) pixels[i * ch + c] = rgba[i * 4 + c];
+    return true;
+}
+
+// Radiance RGBE (.hdr) as an 8-bit caller of stb gets it: new-style run-length rows or flat pixels, each RGBE quadruple to float
+// (mantissa * 2^(e - 136)), then stb's tone curve for 8-bit callers: (float) pow(v, 1 / 2.2f) * 255 + 0.5f, clamped, truncated.
+inline bool rt_decode_hdr(const std::vector<unsigned char>& file, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
+{
+    size_t pos = 0;
+    auto line = [&]() { std::string s; while (pos < file.size() && file[pos] != '\n') s += (char) file[pos++]; pos++; return s; };
+    auto get = [&]() { return pos < file.size() ? (int) file[pos++] : (pos++, 0); };
+    std::string first = line();
+    if (first != "#?RADIANCE" && first != "#?RGBE") return false;
+    bool rgbe_format = false;
+    for (;;) {
+        if (pos >= file.size()) return false;
+        std::string s = line();
+        if (s.empty()) break;
+        if (s == "FORMAT=32-bit_rle_rgbe") rgbe_format = true;
+    }
+    if (!rgbe_format) return false;
+    std::string size = line();
+    if (size.compare(0, 3, "-Y ") != 0) return false;
+    char* end = nullptr;
+    h = (int) std::strtol(size.c_str() + 3, &end, 10);
+    while (*end == ' ') end++;
+    if (std::strncmp(end, "+X ", 3) != 0) return false;
+    w = (int) std::strtol(end + 3, nullptr, 10);
+    if (w <= 0 || h <= 0 || w > (1 << 24) || h > (1 << 24) || (uint64_t) w * h > (1ull << 28) || (uint64_t) w * h > (uint64_t) file.size() * 128) return false;
+    ch = 3;
+    std::vector<float> rgb((size_t) w * h * 3, 0.f);
+    auto convert = [](float* out, const unsigned char* in) {
+        if (in[3] != 0) { float f = (float) std::ldexp(1.0f, in[3] - (128 + 8)); out[0] = in[0] * f; out[1] = in[1] * f; out[2] = in[2] * f; }
+        else out[0] = out[1] = out[2] = 0.f;
+    };
+    size_t flat_from = 0;                 // first pixel still to be read as flat data
+    bool flat = w < 8 || w >= 32768;
+    if (!flat) {
+        std::vector<unsigned char> row((size_t) w * 4);
+        for (int j = 0; j < h && !flat; j++) {
+            int c1 = get(), c2 = get(), len = get();
+            if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+                // not a run-length row: stb takes these four bytes as the picture's FIRST pixel and reads everything after them flat
+                unsigned char px[4] = { (unsigned char) c1, (unsigned char) c2, (unsigned char) len, (unsigned char) get() };
+                convert(&rgb[0], px);
+                flat = true; flat_from = 1;
+                break;
+            }
+            len = (len << 8) | get();
+            if (len != w) return false;
+            for (int k = 0; k < 4; k++)
+                for (int i = 0; i < w;) {
+                    int count = get();
+                    if (pos > file.size()) return false;
+                    if (count > 128) { int value = get(); count -= 128; if (count > w - i) return false; for (int z = 0; z < count; z++) row[(size_t) i++ * 4 + k] = (unsigned char) value; }
+                    else { if (count > w - i || count == 0) return false; for (int z = 0; z < count; z++) row[(size_t) i++ * 4 + k] = (unsigned char) get(); }
+                }
+            for (int i = 0; i < w; i++) convert(&rgb[((size_t) j * w + i) * 3], &row[(size_t) i * 4]);
+        }
+    }
+    if (flat)
+        for (size_t i = flat_from; i < (size_t) w * h; i++) {
+            unsigned char px[4];
+            for (int k = 0; k < 4; k++) px[k] = (unsigned char) get();
+            convert(&rgb[i * 3], px);
+        }
+    pixels.resize(rgb.size());
+    const float gamma_i = 1.0f / 2.2f;
+    for (size_t i = 0; i < rgb.size(); i++) {
+        float z = (float) std::pow(rgb[i] * 1.0f, gamma_i) * 255 + 0.5f;
+        if (z < 0) z = 0;
+        if (z > 255) z = 255;
+        pixels[i] = (unsigned char) (int) z;
+    }
+    return true;
+}
+
 inline bool rt_load_image(const char* path, std::vector<unsigned char>& pixels, int& w, int& h, int& ch)
 {
     std::vector<unsigned char> file;
     if (!rt_read_file(path, file)) return false;
-    // stb's order of trying (of the formats read here): PNG, BMP, GIF, JPEG, PNM, and TGA last, which has no signature
-    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_bmp(file, pixels, w, h, ch) || rt_decode_gif(file, pixels, w, h, ch) || rt_decode_jpeg(file, pixels, w, h, ch) ||
-           rt_decode_ppm(file, pixels, w, h, ch) || rt_decode_tga(file, pixels, w, h, ch);
+    // stb's order of trying: PNG, BMP, GIF, PSD, PIC, JPEG, PNM, HDR, and TGA last, which has no signature
+    return rt_decode_png(file, pixels, w, h, ch) || rt_decode_bmp(file, pixels, w, h, ch) || rt_decode_gif(file, pixels, w, h, ch) ||
+           rt_decode_psd(file, pixels, w, h, ch) || rt_decode_pic(file, pixels, w, h, ch) || rt_decode_jpeg(file, pixels, w, h, ch) ||
+           rt_decode_ppm(file, pixels, w, h, ch) || rt_decode_hdr(file, pixels, w, h, ch) || rt_decode_tga(file, pixels, w, h, ch);
 }
 
 // 8-bit RGB/RGBA/gray PNG.  flip_vertically mirrors stbi_flip_vertically_on_write(true) (raytracing.cpp:124): the
