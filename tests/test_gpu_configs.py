@@ -107,18 +107,19 @@ def test_config3_soup_with_png_textures_through_the_host_loader(R, tmp_path):
 
 
 def test_soup_with_jpeg_textures_through_the_host_loader(R, tmp_path, golden_dir):
-    """The same chain with JPEG map_Kd files (what OBJ assets usually ship): the soup's four materials point at four files of
-    tests/golden/images.npz -- baseline 4:2:0, progressive, grey (ONE channel: the reference indexes such a texture with its own
-    channel count and reads three neighbouring bytes, texture.hpp:115-122) and Adobe CMYK.  (1) the flattened texels equal what the
+    """The same chain with JPEG (what OBJ assets usually ship), PNG and GIF map_Kd files: the soup's six materials point at six files of
+    tests/golden/images.npz -- JPEG baseline 4:2:0, progressive, grey (ONE channel: the reference indexes such a texture with its own
+    channel count and reads three neighbouring bytes, texture.hpp:115-122) and Adobe CMYK, a grey + alpha PNG (two channels) and a GIF
+    (four).  (1) the flattened texels equal what the
     reference's loader made of those files (the fixture); (2) RT_MODE_FAST_FP64 against the oracle on the same streams: <= 1e-9
     relative on >= 99.5 % of the pixels, ray counts within 0.2 %; (3) RT_MODE_FAST_FP32: relative RMSE <= 5 %, no firefly."""
     from raytracing_amd.host_scenes import HostScene
     from raytracing_amd.tools.make_mesh import write_soup
     g = np.load(os.path.join(golden_dir, "images.npz"))
     names = [str(n) for n in g["names"]]
-    files = ("rgb420_200x120.jpg", "prog420.jpg", "grey_q85.jpg", "cmyk.jpg")
+    files = ("rgb420_200x120.jpg", "prog420.jpg", "grey_q85.jpg", "cmyk.jpg", "grey_alpha.png", "transparent.gif")     # 3, 3, 1, 3, 2 and 4 channels
     path = str(tmp_path / "soup.obj")
-    n = write_soup(path, n_tri=6000, n_mats=4, tex_size=8, extent=6.0, edge=0.7, seed=9)
+    n = write_soup(path, n_tri=6000, n_mats=6, tex_size=8, extent=6.0, edge=0.7, seed=9)
     mtl = str(tmp_path / "soup.mtl")
     text = open(mtl).read()
     for k, name in enumerate(files):
@@ -129,10 +130,10 @@ def test_soup_with_jpeg_textures_through_the_host_loader(R, tmp_path, golden_dir
     w, h, spp, depth = 96, 64, 16, 12
     hs = HostScene.obj(path, w, h, 1, cam_pos=(1.0, 5.0, 18.0), cam_lookat=(0, 0, 0), fov=40.0)
     d = hs.arrays()
-    assert len(d["prim_kind"]) == n and int((d["tex_kind"] == 3).sum()) == 4
+    assert len(d["prim_kind"]) == n and int((d["tex_kind"] == 3).sum()) == 6
     for k, name in enumerate(files):
         iw, ih, ich, _ = [int(v) for v in g["dims%d" % names.index(name)]]
-        ti = int(d["mat_tex"][int(d["prim_mat"][k * 1500 + 7])])
+        ti = int(d["mat_tex"][int(d["prim_mat"][k * 1000 + 7])])
         tw, th, tch, color_based, off = [int(x) for x in d["tex_data"][ti][:5]]
         assert (tw, th, tch, color_based) == (iw, ih, ich, 1), name
         assert np.array_equal(d["tex_pixels"][off:off + iw * ih * ich], g["pixels%d" % names.index(name)]), name
