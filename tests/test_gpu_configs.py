@@ -416,3 +416,30 @@ def test_bench_prints_one_json_line_with_the_contract_fields(R):
     assert d["image"]["same_streams"]["rays_gpu"] == d["image"]["same_streams"]["rays_cpu"]
     assert d["fp32_mode"]["dtype"] == "f32" and d["fp32_mode"]["value"] > 0
 
+
+def test_bench_under_the_launcher_with_two_ranks(R):
+    """bench.py as the driver starts it for N > 1 (python -m torch.distributed.run, one rank per GPU), rehearsed on this one-GPU box with two
+    ranks that share the device and reduce through the host (RT_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device): rank 0
+    prints the one line, n_gpus = 2, each rank rendered half of the samples, and the frame's ray count is the single-rank frame's."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    small = ["--width", "160", "--height", "90", "--spp", "8", "--steps", "2", "--warmup", "1", "--mesh-level", "3", "--no-cpu", "--image-width", "0", "--no-fp32"]
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[:500]
+    two = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, capture_output=True, text=True, timeout=200)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and single["n_gpus"] == 1 and two["steps"] == 2 and two["value"] > 0
+    assert two["config"]["rays_per_step"] == single["config"]["rays_per_step"], "streams are keyed by the global sample index: same frame for any N"
+    assert "gloo" in two["config"]["parallelism"] or "2" in two["config"]["parallelism"]
+
