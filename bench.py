@@ -365,7 +365,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if is_fp64 else "f32",
             "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth, "mode": MODES[args.mode].replace("MODE_", "RT_MODE_"),
-                       "parallelism": f"{args.split} split over {world} rank(s), {'RCCL' if backend == 'nccl' else backend + ' (rehearsal: ranks may share a GPU)'} reduce of the accumulation buffer" if world > 1 else "single GPU",
+                       "parallelism": f"{args.split} split over {world} rank(s), {'RCCL' if backend == 'nccl' else backend + ' (rehearsal: ranks may share a GPU)'} reduce of the accumulation buffer" if world > 1 else ("single GPU" if not grouped else f"single GPU, {backend} process group of one (every collective of the N > 1 path issued)"),
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims),
                        "zero_direction_ray_share": round(zero_share, 4),
                        "zero_direction_note": "share of rays_per_step that are rays with direction (0,0,0): phong leaves wo unset (material.hpp:225-229,252-254); the "
