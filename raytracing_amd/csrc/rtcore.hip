@@ -448,6 +448,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         t.kind = d->tex_kind[i];
         if (t.kind == RT_TEX_CONSTANT) { t.rgb[0] = (R) td[0]; t.rgb[1] = (R) td[1]; t.rgb[2] = (R) td[2]; }
         else if (t.kind == RT_TEX_CHECKER) { t.a = (int) td[0]; t.b = (int) td[1]; }
+        else if (td[0] <= 0) { t.kind = RT_TEX_CONSTANT; t.rgb[0] = R(0); t.rgb[1] = R(1); t.rgb[2] = R(1); }   // an image that failed to load is cyan everywhere (texture.hpp:97-99)
         else { t.a = (int) td[0]; t.b = (int) td[1]; t.ch = (int) td[2]; t.color_based = td[3] != 0; t.offset = (uint32_t) td[4]; need_uv = true; }
     }
     std::vector<rt::Xform<R>> xforms(d->n_xforms);
@@ -576,7 +577,8 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     for (int i = 0; i < desc->n_prims; i++) s->only_spheres &= desc->prim_kind[i] != RT_PRIM_TRIANGLE;
     for (int i = 0; i < desc->n_lights; i++) s->only_spheres &= is_rect(desc->light_kind[i]);
     for (int i = 0; i < desc->n_mats; i++) s->only_spheres &= desc->mat_kind[i] != RT_MAT_PHONG && (desc->mat_kind[i] != RT_MAT_FOG || s->has_volume);
-    for (int i = 0; i < desc->n_tex; i++) s->only_spheres &= desc->tex_kind[i] == RT_TEX_CONSTANT || desc->tex_kind[i] == RT_TEX_CHECKER;
+    for (int i = 0; i < desc->n_tex; i++)       // (an image texture without texels is uploaded as the constant it evaluates to)
+        s->only_spheres &= desc->tex_kind[i] == RT_TEX_CONSTANT || desc->tex_kind[i] == RT_TEX_CHECKER || (desc->tex_kind[i] == RT_TEX_IMAGE && desc->tex_data[(size_t) i * RT_TEX_STRIDE] <= 0);
     if (const char* env = std::getenv("RT_LEAN_SPHERES")) s->only_spheres &= std::atoi(env) != 0;      // 0: the general variant (A/B)
     if (hipMalloc((void**) &s->counters, 16 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess ||
         hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_EHIP, "allocating counters/events failed"); }
