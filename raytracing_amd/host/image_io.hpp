@@ -79,6 +79,7 @@ inline bool rt_decode_png(const std::vector<unsigned char>& file, std::vector<un
         int pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
         if (pw > 0 && ph > 0) total += (((size_t) pw * bits_px + 7) / 8 + 1) * ph;
     }
+    if (total > (size_t) idat.size() * 1100 + 4096) return false;      // deflate expands at most ~1030 : 1; a header that promises more is not believed
     std::vector<unsigned char> raw(total);
     uLongf raw_len = (uLongf) raw.size();
     int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size());
@@ -392,7 +393,7 @@ inline bool rt_decode_gif(const std::vector<unsigned char>& file, std::vector<un
     w = r.u16(); h = r.u16();
     int flags = r.u8(), background = r.u8();
     r.u8();
-    if (w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28)) return false;
+    if (w <= 0 || h <= 0 || (uint64_t) w * h > (1ull << 28) || (uint64_t) w * h > (uint64_t) file.size() * 4096) return false;   // (LZW packs at most a few thousand pixels into a code)
     struct entry { unsigned char r, g, b, a; };
     std::vector<entry> global(256, entry{ 0, 0, 0, 0 }), local(256, entry{ 0, 0, 0, 0 });
     auto read_table = [&](std::vector<entry>& t, int n, int transparent) {
@@ -520,6 +521,7 @@ inline bool rt_decode_psd(const std::vector<unsigned char>& file, std::vector<un
     int depth = r.u16();
     if ((depth != 8 && depth != 16) || r.u16() != 3) return false;          // RGB only
     if (ww == 0 || hh == 0 || ww > (1u << 24) || hh > (1u << 24) || (uint64_t) ww * hh > (1ull << 28)) return false;
+    if ((uint64_t) ww * hh > (uint64_t) file.size() * 128) return false;     // PackBits expands at most 64 : 1
     r.skip(r.u32()); r.skip(r.u32()); r.skip(r.u32());                       // mode data, image resources, layers
     int compression = r.u16();
     if (compression > 1 || r.pos > file.size()) return false;
@@ -564,7 +566,7 @@ inline bool rt_decode_pic(const std::vector<unsigned char>& file, std::vector<un
     r.skip(92);
     w = r.u16(); h = r.u16();
     r.skip(8);                                            // ratio, fields, pad
-    if (w <= 0 || h <= 0) return false;
+    if (w <= 0 || h <= 0 || (uint64_t) w * h > (uint64_t) file.size() * 65536) return false;   // (a mixed run holds up to 65535 pixels)
     struct packet { int type, channel; } packets[10];
     int n_packets = 0, carried = 0, chained;
     do {

@@ -184,6 +184,7 @@ struct decoder {
         n_comp = byte();
         if (height <= 0 || width <= 0 || (n_comp != 1 && n_comp != 3 && n_comp != 4) || len != 8 + 3 * n_comp) return false;
         if ((uint64_t) width * height > (1ull << 28)) return false;
+        if ((uint64_t) width * height > (uint64_t) size * 256) return false;   // an MCU costs at least a few bytes: a header that promises more is not believed (and nothing is allocated for it)
         h_max = v_max = 1; rgb_ids = 0;
         for (int i = 0; i < n_comp; i++) {
             component& c = comp[i];
