@@ -354,7 +354,7 @@ def main():
                     "flop_per_ray": {"fp32": round(flop32, 1), "fp64": round(flop64, 1)}, "record_bytes_per_ray": round(bytes_per_ray, 1),
                     "node_record_bytes": node_bytes, "boxes_per_node_record": boxes_per_node, "leaf_record_bytes": leaf_bytes, "scene_MB": round(scene_mb, 1),
                     "note": "No dense contraction (no MFMA) and no HBM stream: node and primitive records are served by L1/L2/Infinity Cache (hbm_frac = measured "
-                            "memory-side bytes / time / 8 TB/s).  The roof that binds is VALU issue under wave64 divergence: frac = algorithmic flops "
+                            "memory-side bytes / time / 8 TB/s).  The nearest roof is VALU issue under wave64 divergence (PMC: vector ALU 62 % busy; waves spend 52 % of their cycles waiting on dependent round trips, profiles/r02_i_pmc_wave_stalls_*): frac = algorithmic flops "
                             "(24 per fp32 box test, 40 per leaf test, 150 per ray of shading; leaf + shading in the result precision) / kernel time, "
                             "against the vector peaks 157.3 (fp32) / 78.6 (fp64) TFLOP/s weighted by this mix (`peak`).  l1_frac = algorithmic record "
                             "bytes / time against the vector-L1 peak"}
