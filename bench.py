@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the MI355X path-tracing core on BASELINE.json's workload.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment); started WITHOUT a launcher, bench.py starts those N ranks itself as a child process -- before it makes
+any GPU call -- relays rank 0's one JSON line and exits with the launcher's return code.
 
 A *step* is one pass of the hot path over one frame: every rank renders its share of the frame's samples with the
 HIP kernels (rt_render), the per-rank accumulation buffers are summed onto rank 0 by an RCCL reduce over xGMI,
@@ -169,8 +173,28 @@ REF_SPP = 8        # samples per pixel of the cpu_reference leg
 OBJ_CAMERA = {"obj": (0, 1.8, 5.0, 0, 1.0, 0, 40.0), "soup": (0, 5.0, 75.0, 0, 0, 0, 40.0)}     # position, look-at, fov of the OBJ workloads
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (python -m torch.distributed.run, one per GPU, rendezvous on
+    127.0.0.1) as a CHILD process before this process has made any GPU call, relay rank 0's one JSON line and exit with the launcher's
+    return code.  (Never an exec: a process that has touched the GPU must not be replaced.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)          # stderr passes through
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(res.returncode if res.returncode != 0 or lines else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                     # does not return
     if args.workload == "soup":
         args.cpu_spp = 1                  # bounded sample: a soup ray costs the CPU tree hundreds of box tests
     import torch
@@ -183,9 +207,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 needs one rank per GPU: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+        args.gpus = world                 # the launcher decides
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path is the only path")
     # one rank per GPU (RCCL).  RT_BENCH_BACKEND=gloo is for rehearsing the N > 1 path on a box with fewer GPUs than ranks:
@@ -211,28 +233,50 @@ def main():
     mode = getattr(R, MODES[args.mode])
     is_fp64 = args.mode in ("fp64", "fp64ref")
     dtype = torch.float64 if is_fp64 else torch.float32
+    # The scene is built ONCE per node: rank 0 writes the OBJ, runs it through the OBJ loader and the reference BVH builder of the host
+    # mirror and -- for N > 1 -- saves the flattened description with rt_scene_desc_save (the binary scene cache); the
+    # other ranks wait at a barrier and load that file instead of repeating eight 100 MB OBJ writes, parses and tree builds.
+    obj_path, host = None, None
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_bench_scene_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.rtscene")
+    if rank == 0:
+        if args.workload == "random_spheres":
+            host = HostScene.random_spheres(w, h, 1)
+        elif args.workload == "soup":
+            from raytracing_amd.tools.make_mesh import write_soup
+            obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_soup_{args.soup_tris}_{os.getpid()}.obj")
+            write_soup(obj_path, args.soup_tris, 64, args.soup_tex)
+            host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["soup"][0:3], cam_lookat=OBJ_CAMERA["soup"][3:6], fov=OBJ_CAMERA["soup"][6])
+        else:
+            obj_path = args.obj
+            if obj_path == "auto":
+                from raytracing_amd.tools.make_mesh import write_scene
+                obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_blob_l{args.mesh_level}_{os.getpid()}.obj")
+                write_scene(obj_path, args.mesh_level)
+            host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["obj"][0:3], cam_lookat=OBJ_CAMERA["obj"][3:6], fov=OBJ_CAMERA["obj"][6])
+        n_prims = int(host.desc.contents.n_prims)
+        if world > 1:
+            from raytracing_amd.rtcore import _check, load_library
+            _check(load_library().rt_scene_desc_save(host.desc, os.fsencode(cache + ".tmp")))
+            os.replace(cache + ".tmp", cache)
+        scene = host.upload()
+    if world > 1:
+        dist.barrier()                      # the cache file is complete
+        if rank != 0:
+            arrays = R.load_scene_cache(cache)
+            n_prims = len(arrays["prim_kind"])
+            scene = R.Scene(arrays)
+            del arrays
+        dist.barrier()                      # everyone has read it
+        if rank == 0:
+            os.unlink(cache)
     if args.workload == "random_spheres":
-        host = HostScene.random_spheres(w, h, 1)
         workload = f"BASELINE configs[1]: random_scene (reference demo.hpp:17-60, rand() seed 1) + area light, {w}x{h}, {spp} spp, max_depth {args.depth}"
     elif args.workload == "soup":
-        from raytracing_amd.tools.make_mesh import write_soup
-        obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_soup_{args.soup_tris}_r{rank}.obj")
-        write_soup(obj_path, args.soup_tris, 64, args.soup_tex)
-        host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["soup"][0:3], cam_lookat=OBJ_CAMERA["soup"][3:6], fov=OBJ_CAMERA["soup"][6])
-        n_tri = int(host.desc.contents.n_prims)
-        workload = (f"BASELINE configs[3]: {n_tri}-triangle soup in [-50,50]^3, 64 MTL materials each with a {args.soup_tex}^2 PNG map_Kd, emissive quad, "
+        workload = (f"BASELINE configs[3]: {n_prims}-triangle soup in [-50,50]^3, 64 MTL materials each with a {args.soup_tex}^2 PNG map_Kd, emissive quad, "
                     f"through the OBJ loader and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
     else:
-        obj_path = args.obj
-        if obj_path == "auto":
-            from raytracing_amd.tools.make_mesh import write_scene
-            obj_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_blob_l{args.mesh_level}_r{rank}.obj")
-            n_tri = write_scene(obj_path, args.mesh_level)
-        host = HostScene.obj(obj_path, w, h, 1, cam_pos=OBJ_CAMERA["obj"][0:3], cam_lookat=OBJ_CAMERA["obj"][3:6], fov=OBJ_CAMERA["obj"][6])
-        n_tri = int(host.desc.contents.n_prims)
-        workload = (f"BASELINE configs[2]: procedural OBJ mesh ({n_tri} triangles, diffuse/specular MTL + emissive quad) through the OBJ loader "
+        workload = (f"BASELINE configs[2]: procedural OBJ mesh ({n_prims} triangles, diffuse/specular MTL + emissive quad) through the OBJ loader "
                     f"and the reference BVH builder, {w}x{h}, {spp} spp, max_depth {args.depth}")
-    scene = host.upload()
 
     # this rank's share of the frame's samples
     k0, k1 = sample_range(rank, world, spp) if args.split == "spp" else (0, spp)
@@ -263,31 +307,34 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    rays = 0
+    rays = 0            # trace() calls past the depth check: what the reference counts as a ray
+    untraced = 0        # of those, the zero-direction segments the kernel finishes without walking the tree (rt_render_stats.untraced_rays)
     kernel_ms = []
     for _ in range(args.steps):
         st = step()
         rays += st["rays"]
+        untraced += st["untraced_rays"]
         kernel_ms.append(st["kernel_ms"])
     fence()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(rays), elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(rays), float(untraced), elapsed], dtype=torch.float64, device="cuda")
     if grouped:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        total_rays, elapsed = float(tot[0]), float(mx[1])
-    else:
-        total_rays = float(tot[0])
+        elapsed = float(mx[2])
+    reference_rays = float(tot[0])                  # all trace() calls of all ranks
+    total_rays = float(tot[0]) - float(tot[1])      # the metric: rays that underwent a BVH traversal
 
     if rank == 0:
         # test counts for the roofline: one diagnostic launch (counting kernel variant) on a 1-spp sample of this rank's work
         probe = scene.render(accum.data_ptr(), w, h, k0, k0 + 1, args.depth, mode, seed=1, stream=stream, flags=R.FLAG_COUNT_TESTS, y_begin=y0, y_end=y1)
-        box_per_ray = probe["box_tests"] / max(probe["rays"], 1)
-        leaf_per_ray = probe["leaf_tests"] / max(probe["rays"], 1)
+        probe_traced = max(probe["rays"] - probe["untraced_rays"], 1)
+        box_per_ray = probe["box_tests"] / probe_traced           # per TRACED ray: an untraced segment costs no test and is charged no flop
+        leaf_per_ray = probe["leaf_tests"] / probe_traced
         zero_share = probe["zero_direction_rays"] / max(probe["rays"], 1)
-        rays_per_launch = rays / max(args.steps, 1)
+        rays_per_launch = (rays - untraced) / max(args.steps, 1)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         secs = avg_ms * 1e-3
         fast = args.mode in ("fp64", "fp32")
@@ -305,15 +352,15 @@ def main():
         peak_mix = rays_per_launch * flop_per_ray / time_at_peak / 1e12
         valu_frac = time_at_peak / secs
         # OBJ-loader scenes (triangles + phong only) walk the quantised four-wide nodes by default (rtcore.hip, RT_QNODES overrides)
-        quantised = os.environ.get("RT_QNODES", "1" if args.workload in ("obj", "soup") else "0") != "0" and fast
+        kernel_name = scene.kernel_name(mode)
+        quantised = fast and kernel_name.split(",")[2].strip() == "true"            # render_wave_kernel<R, count, wide nodes, scene class>
         # a fast-mode node record is 64 B and holds its children's boxes: four quantised ones or two fp32 ones
         node_bytes = 64.0 if fast else (56.0 if is_fp64 else 32.0)
         boxes_per_node = (4 if quantised else 2) if fast else 1
         leaf_bytes = 96.0 if is_fp64 else 48.0
         bytes_per_ray = box_per_ray * node_bytes / boxes_per_node + leaf_per_ray * leaf_bytes
         fetch_gbs = rays_per_launch * bytes_per_ray / secs / 1e9
-        d = host.desc.contents
-        scene_mb = (d.n_prims * node_bytes * 1.2 / boxes_per_node + d.n_prims * leaf_bytes) / 1e6      # ~0.6 binary SAH nodes per primitive (half as many wide ones) + primitive records
+        scene_mb = (n_prims * node_bytes * 1.2 / boxes_per_node + n_prims * leaf_bytes) / 1e6      # ~0.6 binary SAH nodes per primitive (half as many wide ones) + primitive records
         # HBM-side bytes per launch: bytes per ray measured with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md) on this workload and mode at reduced spp (profiles/hbm_traffic.json, written by
         # tools/hbm_traffic.py from a run of this same command under the profiler), scaled by this launch's ray count; null when no
@@ -321,30 +368,34 @@ def main():
         traffic, traffic_src = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                rec = json.load(f).get(f"{args.workload}:{int(d.n_prims)}:{args.mode}:{w}x{h}:d{args.depth}")
+                rec = json.load(f).get(f"{args.workload}:{n_prims}:{args.mode}:{w}x{h}:d{args.depth}")
             if rec:
                 traffic = int(rec["bytes_per_ray"] * rays_per_launch)
                 traffic_src = f"profiles/hbm_traffic.json: {rec['bytes_per_ray']:.1f} B/ray measured at {rec.get('spp_profiled')} spp ({rec.get('round', 'r01')}), x this launch's rays"
         except (OSError, ValueError):
             pass
         hbm_frac = round(traffic / secs / 1e9 / PEAK_HBM_GBS, 4) if traffic is not None else None
-        # unit utilisation of the same kernel from the latest PMC passes on file for this workload and mode (tools/collect_profiles.py):
-        # share of cycles the vector ALUs / the texture-address units are busy.  Stored, not measured by this run -- the line says so.
+        # unit utilisation of the SAME kernel variant (rt_render_kernel_name: the kernels are compiled per scene class and node format) from
+        # the PMC passes on file for this workload and mode (tools/collect_profiles.py): the latest round's, the longest launch's.  Stored,
+        # not measured by this run -- the line says so.  A file whose kernel name differs (an older kernel) is not used.
         pmc = None
         try:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_wave_kernel_{args.mode}_{args.workload}_4k_16spp.json")))
-            if files and (w, h) == (3840, 2160):
-                with open(files[-1]) as f:
-                    derived = json.load(f).get("derived", {})
-                for name, v in derived.items():
-                    if ", false," in name:          # the timed kernel, not its counting twin
-                        pmc = {"valu_busy": round(v["valu_busy"], 3), "ta_busy": round(v["ta_busy"], 3), "waves_per_simd": round(v.get("waves_per_simd", 0.0), 2),
-                               "source": f"profiles/{os.path.basename(files[-1])}: rocprofv3 --pmc passes of this command at 16 spp, not measured by this run"}
-        except (OSError, ValueError, KeyError):
+            import re
+            files = glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_wave_kernel_{args.mode}_{args.workload}_4k_*spp.json"))
+            key = lambda f: (re.match(r"(r\d+_[a-z]+)_", os.path.basename(f)).group(1), int(re.search(r"_(\d+)spp\.json$", f).group(1)))
+            for f in sorted(files, key=key, reverse=True) if (w, h) == (3840, 2160) else []:
+                with open(f) as fh:
+                    derived = json.load(fh).get("derived", {})
+                hit = [v for name, v in derived.items() if kernel_name + "(" in name.replace("void ", "")]
+                if hit:
+                    v = hit[0]
+                    pmc = {"valu_busy": round(v["valu_busy"], 3), "ta_busy": round(v["ta_busy"], 3), "waves_per_simd": round(v.get("waves_per_simd", 0.0), 2),
+                           "valu_lane_slots_per_ray": v.get("valu_lane_slots_per_ray"), "wait_any_share_of_wave_cycles": v.get("wait_any_share"),
+                           "source": f"profiles/{os.path.basename(f)}: rocprofv3 --pmc passes of this command at {key(f)[1]} spp, kernel {kernel_name}; not measured by this run"}
+                    break
+        except (OSError, ValueError, KeyError, AttributeError):
             pass
-        kernel_name = {"fp64": "rt::render_wave_kernel<double>", "fp32": "rt::render_wave_kernel<float>", "fp32ref": "rt::render_kernel<float>",
-                       "fp64ref": "rt::render_kernel<double>"}[args.mode]
         assert 0.0 < valu_frac <= 1.0, f"roofline fraction {valu_frac} outside (0, 1]: the cost model or the peak is wrong"
         roofline = {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": round(peak_mix, 1), "unit": "TFLOP/s", "frac": round(valu_frac, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "hbm_peak_GBs": PEAK_HBM_GBS, "pmc": pmc,
@@ -360,19 +411,20 @@ def main():
                             "bytes / time against the vector-L1 peak"}
         out = {
             "metric": "Mrays/s (node), path-traced frame, results in the reference's precision; image RMSE vs the reference CPU path in `image`",
-            "value": round(total_rays / elapsed / 1e6, 2),
+            "value": round(total_rays / elapsed / 1e6, 2),            # rays that walked the tree / wall time
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64" if is_fp64 else "f32",
             "data": "synthetic (procedural scene: random_scene() with rand() seed 1, or the generated OBJ mesh)",
             "config": {"workload": workload, "width": w, "height": h, "spp": spp, "max_depth": args.depth, "mode": MODES[args.mode].replace("MODE_", "RT_MODE_"),
                        "parallelism": f"{args.split} split over {world} rank(s), {'RCCL' if backend == 'nccl' else backend + ' (rehearsal: ranks may share a GPU)'} reduce of the accumulation buffer" if world > 1 else ("single GPU" if not grouped else f"single GPU, {backend} process group of one (every collective of the N > 1 path issued)"),
-                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": int(host.desc.contents.n_prims),
+                       "rays_per_step": int(total_rays / max(args.steps, 1)), "samples_per_step": w * h * spp, "n_primitives": n_prims,
+                       "reference_rays_per_step": int(reference_rays / max(args.steps, 1)),
                        "zero_direction_ray_share": round(zero_share, 4),
-                       "zero_direction_note": "share of rays_per_step that are rays with direction (0,0,0): phong leaves wo unset (material.hpp:225-229,252-254); the "
-                                              "reference traces and counts such a ray, which can only miss in a scene of triangles (polygon.hpp:95-97), so the fast "
-                                              "kernels skip its traversal there (same result, still counted, as SURVEY 8d counts trace() calls); "
-                                              "`value_without_zero_direction_rays` leaves them out of the rate"},
-            "value_without_zero_direction_rays": round(total_rays * (1.0 - zero_share) / elapsed / 1e6, 2),
+                       "ray_count_note": "`value` and rays_per_step count the rays that walked the tree.  The reference counts more (reference_rays_per_step, "
+                                         "`value_reference_ray_count`): phong leaves wo unset (material.hpp:225-229,252-254), so a share of its trace() calls "
+                                         "(zero_direction_ray_share) carries direction (0,0,0); such a ray can only miss in a scene of triangles "
+                                         "(polygon.hpp:95-97) and the fast kernels finish it without a traversal (same result, same sample counts)"},
+            "value_reference_ray_count": round(reference_rays / elapsed / 1e6, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_fp32 and args.mode == "fp64":
@@ -384,8 +436,9 @@ def main():
             st32 = step(R.MODE_FAST_FP32, acc32)
             fence()
             dt32 = time.perf_counter() - t1
-            out["fp32_mode"] = {"value": round(st32["rays"] / dt32 / 1e6, 2), "unit": "Mrays/s", "dtype": "f32", "mode": "RT_MODE_FAST_FP32", "steps": 1,
-                                "ms_per_step": round(dt32 * 1e3, 3), "kernel_ms": round(st32["kernel_ms"], 3), "rays_per_step": st32["rays"]}
+            out["fp32_mode"] = {"value": round((st32["rays"] - st32["untraced_rays"]) / dt32 / 1e6, 2), "unit": "Mrays/s", "dtype": "f32", "mode": "RT_MODE_FAST_FP32", "steps": 1,
+                                "ms_per_step": round(dt32 * 1e3, 3), "kernel_ms": round(st32["kernel_ms"], 3), "rays_per_step": st32["rays"] - st32["untraced_rays"],
+                                "value_reference_ray_count": round(st32["rays"] / dt32 / 1e6, 2)}
             del acc32
         if world == 1 and not args.no_cpu:
             O, osc = oracle_scene(args, host.arrays())
@@ -402,7 +455,8 @@ def main():
         os.dup2(2, 1)
 
     scene.destroy()
-    host.free()
+    if host is not None:
+        host.free()
     if grouped:
         dist.destroy_process_group()
 

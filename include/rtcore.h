@@ -127,7 +127,9 @@ typedef struct rt_scene_desc {
 
 #define RT_FLAG_QUEUE 64         /* A/B: the fast modes through the decoupled kernel (rt_queue.h: per-wave path pools in global memory, lanes hand
                                     finished traversals to full-width shade passes and take queued rays at once).  Same samples and sums as the
-                                    default kernel up to the order of the tile additions.  Scenes with boxes, volumes or instances ignore it. */
+                                    default kernel up to the order of the tile additions.  Scenes with boxes, volumes or instances ignore it.
+                                    The pools are allocated on a scene's first such render and freed by rt_scene_destroy: 2048 pools x 1024 slots
+                                    x 64 B = 128 MiB for RT_MODE_FAST_FP32, x 128 B = 256 MiB for RT_MODE_FAST_FP64. */
 
 #define RT_FLAG_COMPAT_FIXED 128 /* No counterpart in the reference (SURVEY 7 / 9 "compat=fixed"): the reference's estimator with three defects repaired,
                                     for pictures rather than parity.  (1) A specular lobe is a delta and weighs its attenuation: the reference divides by
@@ -150,7 +152,7 @@ typedef struct rt_render_params {
 } rt_render_params;
 
 typedef struct rt_render_stats {
-    uint64_t rays;               /* trace() invocations that traversed the scene (raytracing.cpp:32-37) */
+    uint64_t rays;               /* trace() invocations past the depth check (raytracing.cpp:32-37): what the reference counts as a ray */
     uint64_t rejected_samples;   /* samples zeroed by the NaN/inf test (raytracing.cpp:108-110) */
     double kernel_ms;            /* HIP-event time of the render kernel on params.stream */
     uint64_t box_tests;          /* aabb::intersect calls (aabb.hpp:23-41), only with RT_FLAG_COUNT_TESTS */
@@ -161,6 +163,9 @@ typedef struct rt_render_stats {
     uint64_t phase_ticks[4];     /* RT_FLAG_COUNT_TESTS, fast mode: wave time (100 MHz ticks, summed over waves) in the regenerate, node, leaf and shade phases */
     uint64_t zero_direction_rays; /* RT_FLAG_COUNT_TESTS: of `rays`, those traced with direction (0,0,0): phong leaves `wo` unset (material.hpp:225-229,
                                     252-254), the reference traces that ray all the same (it misses everything) and so counts it */
+    uint64_t untraced_rays;      /* always counted: of `rays`, the segments the fast kernels finished WITHOUT a BVH traversal -- the zero-direction
+                                    rays above in a scene of triangles alone, where such a ray can only miss (polygon.hpp:95-97).  rays - untraced_rays
+                                    is the number of rays that walked the tree (SURVEY 8d's metric).  0 in the reference-order modes, which walk them */
 } rt_render_stats;
 
 /* Copies the scene to HBM on the current device and builds the device layouts.  Replaces the implicit
@@ -173,7 +178,8 @@ int rt_scene_destroy(rt_scene* scene);
  * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
  * double for RT_MODE_REFERENCE_FP64 and RT_MODE_FAST_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
  * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats (= rt_render_wait).  The scene's device must be
- * the current one.  With RT_FLAG_WAVEFRONT the call
+ * the current one.  A scene has ONE set of counters and events: a second rt_render before the first one's rt_render_wait is refused
+ * (RT_EINVAL).  With RT_FLAG_WAVEFRONT the call
  * runs a loop of extend / shade kernels over a path pool (84 B per slot, RT_WF_SLOTS slots, default 2 Mi; allocated on the
  * scene's first such call, freed by rt_scene_destroy), polls a device flag and returns when the samples are done. */
 int rt_render(rt_scene* scene, const rt_render_params* params, void* accum_dev, rt_render_stats* stats);
@@ -182,16 +188,26 @@ int rt_render(rt_scene* scene, const rt_render_params* params, void* accum_dev, 
  * host thread start renders on several devices and collect them afterwards. */
 int rt_render_wait(rt_scene* scene, rt_render_stats* stats);
 
+/* The name (as rocprofv3 lists it, without the argument list) of the kernel an rt_render of this scene with this mode and flags launches:
+ * the render kernels are compiled in variants by scene content and node format, and a profile is only comparable with a run of the same
+ * variant.  No counterpart in the reference.  Host only. */
+int rt_render_kernel_name(rt_scene* scene, int mode, int flags, char* out, size_t out_bytes);
+
 /* One process, several GPUs (no counterpart in the reference, which knows one device): the spp split of SURVEY 8e at the C boundary.
  * Per device: rt_device_set(d), rt_scene_create (the scene is replicated), a buffer, rt_render of that device's share of the global sample
  * indices with stats == NULL; then rt_render_wait on each and ONE rt_frame_reduce: dst_dev (on dst_device) += every src_dev[i] (on
- * src_device[i]), n_values = width*height*3 sums.  The sources reach the destination by peer copies -- one DMA per source over that
- * source's own xGMI link (the links are point to point), double-buffered against the additions; the call waits for all work on the
- * devices involved before it starts and returns when the sum is complete.  Sources on the destination's own device are allowed.
+ * src_device[i]), n_values = width*height*3 sums.  The sources reach the destination by peer copies, each on a stream of its own so that
+ * the (up to 7) copies run together, every one over its source's own xGMI link (the links are point to point); peer access is enabled
+ * once per device pair where the platform offers it (hipDeviceCanAccessPeer), otherwise the copy goes through the host.  The additions
+ * follow on one stream as the copies land.  The call waits for all work on the devices involved before it starts and returns when the
+ * sum is complete.  Sources on the destination's own device are allowed.  Staging buffers (one per source in flight, n_values each),
+ * streams and events are kept per destination device between calls -- a frame is reduced once per frame -- until
+ * rt_frame_reduce_release() frees them (safe to call at any time; the next reduce allocates again).
  * (Across processes -- one rank per GPU -- bench.py sums the same buffers with an RCCL reduce instead: raytracing_amd/parallel.py.) */
 int rt_device_count(int* count_out);
 int rt_device_set(int device);
 int rt_frame_reduce(void* dst_dev, int dst_device, void* const* src_dev, const int* src_device, int n_src, int accum_is_fp64, size_t n_values);
+int rt_frame_reduce_release(void);
 
 /* mean, gamma 0.45, clamp, truncate to 8 bit: raytracing.cpp:115-121.  rgb_dev: n_pixels*3 bytes. */
 int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream);
@@ -204,12 +220,13 @@ int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int sp
 int rt_first_hit(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
                  uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);
 
-/* rt_first_hit for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernel and bit-identical outputs; the device-side
- * staging of rays and results (88 bytes per ray) lives in a static device array of the library (RT_NOALLOC_MAX_RAYS rays = 2.75 MiB
- * per GPU the library runs on, held until the process ends) instead of hipMalloc'd memory: the call allocates and frees nothing.
- * More than RT_NOALLOC_MAX_RAYS rays -> RT_EINVAL.  The scene's device must be the current one.  All calls on one GPU share
- * that GPU's array: calls that overlap on one GPU (two host threads) race; serialise them. */
+/* rt_first_hit for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc / hipFree).  No
+ * counterpart in the reference.  Same arguments, same kernel and bit-identical outputs; the device-side staging of rays and results
+ * (88 bytes per ray) lives in a static device array of the library (RT_NOALLOC_MAX_RAYS rays = 2.75 MiB per GPU the library runs on,
+ * held until the process ends) instead of hipMalloc'd memory: the call allocates and frees nothing.  It is SYNCHRONOUS like
+ * rt_first_hit -- blocking copies from and to the caller's host arrays, the kernel on the null stream, a device synchronise -- so it
+ * is not for use under stream capture.  More than RT_NOALLOC_MAX_RAYS rays -> RT_EINVAL.  The scene's device must be the current one.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two host threads) race; serialise them. */
 #define RT_NOALLOC_MAX_RAYS 32768
 int rt_first_hit_noalloc(rt_scene* scene, const double* rays, size_t n_rays, int32_t* prim, double* t, int32_t* front,
                          uint32_t* n_box, uint32_t* n_leaf, uint64_t* visit_hash);

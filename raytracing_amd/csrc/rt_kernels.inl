@@ -1,5 +1,6 @@
 // raytracing_amd/csrc/rt_kernels.inl -- launcher bodies, included with RT_REAL defined.
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <vector>
 #include "rt_launch.h"
@@ -10,18 +11,34 @@
 
 namespace rt {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: a process that drives several devices (rt_device_set,
+// scene::render(..., devices)) must set it on each of them.  One instance per kernel variant remembers the largest size set so far per
+// device (atomics: renders of different scenes may be launched from different host threads; setting the attribute twice is harmless).
+struct LdsConfigured {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<size_t> bytes[kMaxDevices] = {};
+    std::atomic<size_t>* of_current_device()
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+        return &bytes[dev];
+    }
+};
+
 #ifdef RT_WITH_WAVE
 // one variant of the wave kernel (rt_wave.h); more than 48 KiB of dynamic LDS needs the attribute set once per kernel
 template <typename R, bool kQuant, int kFull>
 hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters)
 {
     if (lds > 48 * 1024) {
-        static thread_local size_t configured = 0;
-        if (lds > configured) {
+        static LdsConfigured done;
+        std::atomic<size_t>* configured = done.of_current_device();
+        if (!configured) return hipErrorInvalidDevice;
+        if (lds > configured->load(std::memory_order_relaxed)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, false, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, true, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
-            configured = lds;
+            configured->store(lds, std::memory_order_relaxed);
         }
     }
     if (count) hipLaunchKernelGGL((render_wave_kernel<R, true, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
@@ -34,12 +51,14 @@ template <typename R, bool kQuant, int kFull>
 hipError_t launch_queue(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, void* pools, unsigned int* locks)
 {
     if (lds > 48 * 1024) {
-        static thread_local size_t configured = 0;
-        if (lds > configured) {
+        static LdsConfigured done;
+        std::atomic<size_t>* configured = done.of_current_device();
+        if (!configured) return hipErrorInvalidDevice;
+        if (lds > configured->load(std::memory_order_relaxed)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_queue_kernel<R, false, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_queue_kernel<R, true, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e != hipSuccess) return e;
-            configured = lds;
+            configured->store(lds, std::memory_order_relaxed);
         }
     }
     if (count) hipLaunchKernelGGL((render_queue_kernel<R, true, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters, static_cast<QSlot<R>*>(pools), locks);
@@ -95,8 +114,10 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     }
 #endif
     if (lds > 48 * 1024) {
-        static thread_local size_t configured = 0;
-        if (lds > configured) {
+        static LdsConfigured done;
+        std::atomic<size_t>* configured = done.of_current_device();
+        if (!configured) return hipErrorInvalidDevice;
+        if (lds > configured->load(std::memory_order_relaxed)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #ifdef RT_WITH_FAST_BVH
@@ -104,7 +125,7 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<RT_REAL, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 #endif
             if (e != hipSuccess) return e;
-            configured = lds;
+            configured->store(lds, std::memory_order_relaxed);
         }
     }
 #ifdef RT_WITH_FAST_BVH

@@ -114,7 +114,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
     const int node_keep = (int) a.node_keep, handoff_min = (int) a.q_handoff_min, shade_starved = (int) a.q_shade_starved;
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    unsigned long long wave_rays = 0, wave_rejected = 0;
+    unsigned long long wave_rays = 0, wave_rejected = 0, wave_untraced = 0;
     VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0; vs.n_zero = 0;
     unsigned long long cyc[4] = { 0, 0, 0, 0 }, t0 = kCount ? wall_clock64() : 0;   // wave time: hand-off, nodes, leaves, shade
     auto lap = [&](int phase) { if (kCount) { const unsigned long long t1 = wall_clock64(); cyc[phase] += t1 - t0; t0 = t1; } };
@@ -148,6 +148,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                 n_hits += n_fin;
                 const unsigned long long want = fin | idle;                 // every lane without a ray now
                 const int k = min(__popcll(want), n_rays);
+                bool skipped = false;
                 if (slot < 0) {
                     const int r = __popcll(want & below);
                     if (r < k) {
@@ -155,9 +156,10 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         q_load_ray(pool + slot, ray);
                         trav_begin(tv, best, ray, stack_base);
-                        if (class_is_obj(kFull) && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) tv.cur = RT_BVH_SENTINEL;   // see rt_wave.h
+                        if (class_is_obj(kFull) && ray.d.x == R(0) && ray.d.y == R(0) && ray.d.z == R(0)) { tv.cur = RT_BVH_SENTINEL; skipped = true; }   // see rt_wave.h
                     }
                 }
+                wave_untraced += (unsigned long long) __popcll(__ballot(skipped));
                 n_rays -= k;
             }
         }
@@ -333,6 +335,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
     if (lane == 0) {
         atomicAdd(&counters[0], wave_rays);
         if (wave_rejected) atomicAdd(&counters[1], wave_rejected);
+        if (wave_untraced) atomicAdd(&counters[15], wave_untraced);
     }
     if (kCount) {
         unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce, nz = vs.n_zero;

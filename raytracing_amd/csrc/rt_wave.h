@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
 
     unsigned long long wave_rays = 0, wave_rejected = 0;   // wave-uniform (scalar registers): counted with a ballot at points where the wave has reconverged
+    unsigned long long wave_untraced = 0;                  // of wave_rays: segments finished without a traversal (zero-direction rays of an OBJ-loader scene, below)
     VisitStats vs; vs.n_box = 0; vs.n_leaf = 0; vs.hash = 0; vs.w_node = vs.w_leaf = vs.w_bounce = 0; vs.n_zero = 0;
 
     bool alive = false, finished = a.max_depth <= 0 || n_items == 0, poisoned = false;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
             else trav_begin(tv, best, ray, stack_base);
         }
         RT_ASM_MARK("; shade: end");
-        wave_rays += (unsigned long long) __popcll(__ballot(zero_ray));
+        { const unsigned long long nz = (unsigned long long) __popcll(__ballot(zero_ray)); wave_rays += nz; wave_untraced += nz; }
         if (kCount && zero_ray) vs.n_zero++;
         wave_rejected += (unsigned long long) __popcll(__ballot(rejected_now));
         lap(3);
@@ -427,6 +428,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     if (lane == 0) {
         atomicAdd(&counters[0], wave_rays);
         if (wave_rejected) atomicAdd(&counters[1], wave_rejected);
+        if (wave_untraced) atomicAdd(&counters[15], wave_untraced);
     }
     if (kCount) {
         unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce, nz = vs.n_zero;

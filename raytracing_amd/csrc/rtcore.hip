@@ -113,7 +113,8 @@ struct rt_scene {
     // rt_queue.h: path pools (per precision) and their locks, allocated on the scene's first decoupled render
     void* q_pools[2] = { nullptr, nullptr };
     unsigned int* q_locks[2] = { nullptr, nullptr };
-    uint32_t q_n_pools = 2048;                // > workgroups the chip holds at once (256 CUs x <= 5 of these workgroups)
+    uint32_t q_n_pools = 2048;                // >= workgroups the chip can hold at once: 256 CUs x at most 8 workgroups of 256 threads (8 waves per SIMD),
+                                              // so a workgroup's try-lock walk over the pools always finds a free one
     uint32_t queue = 0, q_slots = 192, q_handoff_min = 16, q_shade_starved = 16;   // RT_QUEUE / RT_Q_SLOTS / RT_Q_HANDOFF / RT_Q_STARVED
     rt::WfBuffers wf{};                       // RT_MODE_FAST_FP32 path pool, allocated on first use
     std::vector<void*> wf_owned;
@@ -121,6 +122,7 @@ struct rt_scene {
     uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;
     uint32_t xcd_tiles = 0;                   // super-tiles dealt to the XCDs (rt_wave.h): on when tree + records exceed one XCD's L2; RT_XCD_TILES overrides
     uint32_t quantised = 0;                   // fast mode walks the quantised four-wide nodes (RT_QNODES overrides)   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
+    uint32_t stack_pad = 0;                   // RT_STACK_PAD: stack levels reserved beyond what the tree needs (test hook for the > 48 KiB LDS launches)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
 
@@ -551,6 +553,13 @@ int wf_prepare(rt_scene* s)
 
 }  // namespace
 
+// the wave kernel's variant by scene content (rt_device.h class_*): 2 instances, 1 boxes or volumes, 3 an OBJ-loader scene, 5 / 6 / 7 the
+// spheres-and-rects twins of 0 / 1 / 2, 0 the rest
+static uint32_t scene_kinds(const rt_scene* s)
+{
+    return s->d32.view.xforms != nullptr ? (s->only_spheres ? 7 : 2) : ((s->has_box || s->has_volume) ? (s->only_spheres ? 6 : 1) : (s->only_triangles ? 3 : (s->only_spheres && !s->quantised ? 5 : 0)));
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
@@ -597,6 +606,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_STACK_PAD")) s->stack_pad = (uint32_t) std::min(RT_BVH_STACK_MAX, std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_QUEUE")) s->queue = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_Q_SLOTS")) s->q_slots = (uint32_t) std::min(RT_Q_SLOTS_MAX, std::max(64, std::atoi(env)));
     if (const char* env = std::getenv("RT_Q_HANDOFF")) s->q_handoff_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
@@ -636,6 +646,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         return fail(RT_EINVAL, "RT_MODE_FAST_FP64 runs the wave kernel only: RT_FLAG_LEGACY_LOOP and RT_FLAG_WAVEFRONT are fp32 A/B variants");
     if (s->n_lights <= 0)
         return fail(RT_EINVAL, "scene.lights is empty: the reference indexes a null light list on the first diffuse hit (group.hpp:115-119)");
+    if (s->pending) return fail(RT_EINVAL, "a render of this scene is outstanding (its events and counters are in use): call rt_render_wait first");
     int current = -1;
     HIP_TRY(hipGetDevice(&current));
     if (current != s->device) return fail(RT_EINVAL, "the scene lives on device " + std::to_string(s->device) + " but device " + std::to_string(current) + " is current: call rt_device_set first");
@@ -643,7 +654,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
-    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.xcd_tiles = s->xcd_tiles; a.kinds = s->d32.view.xforms != nullptr ? (s->only_spheres ? 7 : 2) : ((s->has_box || s->has_volume) ? (s->only_spheres ? 6 : 1) : (s->only_triangles ? 3 : (s->only_spheres && !s->quantised ? 5 : 0)));
+    a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.xcd_tiles = s->xcd_tiles; a.kinds = scene_kinds(s);
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
         if (s->has_volume) return fail(RT_EINVAL, "RT_FLAG_WAVEFRONT: the extend kernel has no random stream, which a volume's intersection test draws from");
         int rc = wf_prepare(s);
@@ -659,33 +670,37 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
             stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3];
             stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
             for (int k = 0; k < 4; k++) stats->phase_ticks[k] = 0;
-            stats->zero_direction_rays = 0;
+            stats->zero_direction_rays = 0; stats->untraced_rays = 0;
         }
         return RT_OK;
     }
-    HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
-    HIP_TRY(hipEventRecord(s->ev0, st));
     // the decoupled kernel (rt_queue.h) serves the fast modes of scenes without boxes, volumes (their free-flight draw needs the path's
-    // stream inside the traversal) or instances
+    // stream inside the traversal) or instances.  Its pools are allocated -- both or neither -- before anything is queued on the stream.
     const bool fast_mode = p->mode == RT_MODE_FAST_FP64 || p->mode == RT_MODE_FAST_FP32;
     void* q_pools = nullptr; unsigned int* q_locks = nullptr;
     if ((s->queue || (p->flags & RT_FLAG_QUEUE)) && a.kinds == 5) a.kinds = 0;       // the decoupled kernel has no spheres-and-rects twin: its general variant
-    if (fast_mode && (s->queue || (p->flags & RT_FLAG_QUEUE)) && !(p->flags & RT_FLAG_LEGACY_LOOP) && (a.kinds == 0 || a.kinds == 3) && p->max_depth < (1 << 21)) {
-        const int k = p->mode == RT_MODE_FAST_FP64 ? 1 : 0;
-        if (!s->q_pools[k]) {
-            const size_t bytes = (size_t) s->q_n_pools * 4 * RT_Q_SLOTS_MAX * (k ? rt::queue_slot_bytes(0.0) : rt::queue_slot_bytes(0.0f));
-            HIP_TRY(hipMalloc(&s->q_pools[k], bytes));
-            HIP_TRY(hipMalloc((void**) &s->q_locks[k], s->q_n_pools * sizeof(unsigned int)));
-        }
-        HIP_TRY(hipMemsetAsync(s->q_locks[k], 0, s->q_n_pools * sizeof(unsigned int), st));
-        q_pools = s->q_pools[k]; q_locks = s->q_locks[k];
+    const bool decoupled = fast_mode && (s->queue || (p->flags & RT_FLAG_QUEUE)) && !(p->flags & RT_FLAG_LEGACY_LOOP) && (a.kinds == 0 || a.kinds == 3) && p->max_depth < (1 << 21);
+    const int qk = p->mode == RT_MODE_FAST_FP64 ? 1 : 0;
+    if (decoupled && !s->q_pools[qk]) {
+        const size_t bytes = (size_t) s->q_n_pools * 4 * RT_Q_SLOTS_MAX * (qk ? rt::queue_slot_bytes(0.0) : rt::queue_slot_bytes(0.0f));
+        void* pools = nullptr; unsigned int* locks = nullptr;
+        HIP_TRY(hipMalloc(&pools, bytes));
+        const hipError_t e = hipMalloc((void**) &locks, s->q_n_pools * sizeof(unsigned int));
+        if (e != hipSuccess) { (void) hipFree(pools); return fail(RT_EHIP, std::string("hipMalloc of the decoupled kernel's pool locks: ") + hipGetErrorString(e)); }
+        s->q_pools[qk] = pools; s->q_locks[qk] = locks;
+    }
+    HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    if (decoupled) {
+        HIP_TRY(hipMemsetAsync(s->q_locks[qk], 0, s->q_n_pools * sizeof(unsigned int), st));
+        q_pools = s->q_pools[qk]; q_locks = s->q_locks[qk];
         a.q_slots = s->q_slots; a.q_pools = s->q_n_pools; a.q_handoff_min = s->q_handoff_min; a.q_shade_starved = s->q_shade_starved;
     }
     if (q_pools && a.kinds == 0) a.quantised = 0;              // the decoupled kernel's generic variant walks the binary nodes only
     // the kernels launch_render gives the wide nodes to (rt_kernels.inl): wave and decoupled kernel of the variants 0 and 3
     const bool wide = a.quantised != 0 && (a.kinds == 0 || a.kinds == 3) && !(p->flags & RT_FLAG_LEGACY_LOOP);
     if (p->mode == RT_MODE_FAST_FP64) {
-        a.bvh_stack_levels = (uint32_t) (wide ? s->d64.view.wide_stack : s->d64.view.bvh_depth) + 2;
+        a.bvh_stack_levels = (uint32_t) (wide ? s->d64.view.wide_stack : s->d64.view.bvh_depth) + 2 + s->stack_pad;
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st, q_pools, q_locks));
     }
     else if (p->mode == RT_MODE_REFERENCE_FP64) {
@@ -693,13 +708,33 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         HIP_TRY(rt::launch_render(s->d64.view, a, static_cast<double*>(accum_dev), s->counters, st));
     }
     else {
-        if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) (wide ? s->d32.view.wide_stack : s->d32.view.bvh_depth) + 2;
+        if (p->mode == RT_MODE_FAST_FP32) a.bvh_stack_levels = (uint32_t) (wide ? s->d32.view.wide_stack : s->d32.view.bvh_depth) + 2 + s->stack_pad;
         else if ((size_t) s->d32.ops_bytes + s->d32.prims_bytes <= s->lds_limit) { a.lds_ops_bytes = s->d32.ops_bytes; a.lds_prims_bytes = s->d32.prims_bytes; }
         HIP_TRY(rt::launch_render(s->d32.view, a, static_cast<float*>(accum_dev), s->counters, st, q_pools, q_locks));
     }
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
     if (stats) return rt_render_wait(s, stats);
+    return RT_OK;
+}
+
+int rt_render_kernel_name(rt_scene* s, int mode, int flags, char* out, size_t n)
+{
+    if (!s || !out || n == 0) return fail(RT_EINVAL, "scene and an output buffer are required");
+    const bool fp64 = mode == RT_MODE_FAST_FP64 || mode == RT_MODE_REFERENCE_FP64;
+    const bool count = (flags & RT_FLAG_COUNT_TESTS) != 0;
+    std::string name;
+    if ((mode == RT_MODE_FAST_FP64 || mode == RT_MODE_FAST_FP32) && !(flags & (RT_FLAG_LEGACY_LOOP | RT_FLAG_WAVEFRONT))) {
+        uint32_t kinds = scene_kinds(s);
+        const bool queue = (s->queue || (flags & RT_FLAG_QUEUE)) && (kinds == 0 || kinds == 3 || kinds == 5);
+        if (queue && kinds == 5) kinds = 0;
+        const bool wide = s->quantised != 0 && (kinds == 0 || kinds == 3) && !(queue && kinds == 0);
+        name = std::string(queue ? "rt::render_queue_kernel<" : "rt::render_wave_kernel<") + (fp64 ? "double" : "float") + ", " + (count ? "true" : "false") + ", " +
+               (wide ? "true" : "false") + ", " + std::to_string(kinds) + ">";
+    }
+    else if (mode == RT_MODE_FAST_FP32 && (flags & RT_FLAG_WAVEFRONT)) name = "rt::wf_extend_kernel";
+    else name = std::string("rt::render_kernel<") + (fp64 ? "double" : "float") + ", " + (mode == RT_MODE_FAST_FP32 ? "2" : ((size_t) (fp64 ? s->d64.ops_bytes + s->d64.prims_bytes : s->d32.ops_bytes + s->d32.prims_bytes) <= s->lds_limit ? "1" : "0")) + ", " + (count ? "true" : "false") + ">";
+    std::snprintf(out, n, "%s", name.c_str());
     return RT_OK;
 }
 
@@ -723,7 +758,7 @@ int rt_render_wait(rt_scene* s, rt_render_stats* stats)
         for (int k = 0; k < 4; k++) stats->phase_ticks[k] = c[8 + k];
         if (getenv("RT_DEBUG") && c[4]) fprintf(stderr, "[rtcore] node-step census per wave step: inner %.2f leaf %.2f hit-known %.2f no-path %.2f\n", (double) c[2] / 2 / c[4], (double) c[12] / c[4], (double) c[13] / c[4], (double) c[14] / c[4]);
         stats->rays = c[0]; stats->rejected_samples = c[1]; stats->kernel_ms = ms; stats->box_tests = c[2]; stats->leaf_tests = c[3]; stats->wave_node_steps = c[4]; stats->wave_leaf_steps = c[5]; stats->wave_bounces = c[6];
-        stats->zero_direction_rays = c[7];
+        stats->zero_direction_rays = c[7]; stats->untraced_rays = c[15];
     }
     if (current != s->device) (void) hipSetDevice(current);
     return rc;
@@ -742,54 +777,132 @@ int rt_device_set(int device)
     return RT_OK;
 }
 
+// ---- rt_frame_reduce: per-destination-device context (staging buffers, streams, events), created on first use and kept until
+// rt_frame_reduce_release: a frame is reduced once per rendered frame, and two hipMallocs of 199 MB per call were most of its cost.
+namespace {
+struct ReduceCtx {
+    std::vector<void*> stage;               // one staging buffer per source in flight (<= kReduceLanes), each `bytes` large
+    size_t bytes = 0;
+    std::vector<hipStream_t> copy_stream;   // one per staging buffer: the peer copies of different sources run together, each over its
+                                            // source's own xGMI link (the links are point to point)
+    std::vector<hipEvent_t> copied, added;
+    hipStream_t add_stream = nullptr;
+};
+constexpr int kReduceLanes = 8;             // sources copied at once: 7 peers of an 8-GPU node + one for a source on the destination itself
+std::mutex g_reduce_mutex;
+ReduceCtx g_reduce[kMaxDevices];
+bool g_peer_enabled[kMaxDevices][kMaxDevices] = { { false } };
+
+void reduce_release(ReduceCtx& c)
+{
+    for (void* p : c.stage) if (p) (void) hipFree(p);
+    for (hipStream_t st : c.copy_stream) if (st) (void) hipStreamDestroy(st);
+    for (hipEvent_t e : c.copied) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : c.added) if (e) (void) hipEventDestroy(e);
+    if (c.add_stream) (void) hipStreamDestroy(c.add_stream);
+    c = ReduceCtx();
+}
+
+// with dst_device current: `lanes` staging buffers of `bytes` each, with their streams and events
+int reduce_prepare(ReduceCtx& c, int lanes, size_t bytes)
+{
+    if (c.bytes < bytes) {                  // grow: drop the old buffers first (a frame geometry change, rare)
+        for (void*& p : c.stage) { if (p) (void) hipFree(p); p = nullptr; }
+        c.stage.clear();
+        c.bytes = bytes;
+    }
+    if (!c.add_stream) HIP_TRY(hipStreamCreateWithFlags(&c.add_stream, hipStreamNonBlocking));
+    while ((int) c.stage.size() < lanes) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, c.bytes));
+        c.stage.push_back(p);
+    }
+    while ((int) c.copy_stream.size() < lanes) {
+        hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c.copy_stream.push_back(st);
+        HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        c.copied.push_back(e0);
+        HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        c.added.push_back(e1);
+    }
+    return RT_OK;
+}
+
+// with dst current: let dst's DMA engines and kernels read src's memory directly (xGMI), once per ordered pair.  Where the platform
+// has no peer path hipMemcpyPeerAsync still works (it stages through the host), so a refusal is not an error.
+void enable_peer(int dst, int src)
+{
+    if (dst == src || dst < 0 || src < 0 || dst >= kMaxDevices || src >= kMaxDevices || g_peer_enabled[dst][src]) return;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst, src) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(src, 0);
+        if (e != hipSuccess) (void) hipGetLastError();       // hipErrorPeerAccessAlreadyEnabled (someone else enabled it) is fine: clear it
+    }
+    g_peer_enabled[dst][src] = true;                          // asked once, whatever the answer
+}
+}  // namespace
+
 int rt_frame_reduce(void* dst_dev, int dst_device, void* const* src_dev, const int* src_device, int n_src, int accum_is_fp64, size_t n_values)
 {
     if (!dst_dev || n_src < 0 || (n_src && (!src_dev || !src_device))) return fail(RT_EINVAL, "dst_dev and n_src source buffers with their devices are required");
     if (n_src == 0 || n_values == 0) return RT_OK;
     if (n_values > (size_t) 0x7fffffff * 256) return fail(RT_EINVAL, "rt_frame_reduce: buffer too large");
+    if (dst_device < 0 || dst_device >= kMaxDevices) return fail(RT_EUNSUPPORTED, "device index beyond the library's per-device table");
+    for (int i = 0; i < n_src; i++) {
+        if (!src_dev[i]) return fail(RT_EINVAL, "a source buffer is NULL");
+        if (src_device[i] < 0 || src_device[i] >= kMaxDevices) return fail(RT_EUNSUPPORTED, "device index beyond the library's per-device table");
+    }
     const size_t bytes = n_values * (accum_is_fp64 ? 8 : 4);
     int current = -1;
     HIP_TRY(hipGetDevice(&current));
-    if (current != dst_device) HIP_TRY(hipSetDevice(dst_device));
+    std::lock_guard<std::mutex> lock(g_reduce_mutex);
     int rc = RT_OK;
     auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
-    // two staging buffers on the destination: the peer copy of source i + 1 (a DMA over that source's own xGMI link) runs while source i is added
-    void* stage[2] = { nullptr, nullptr };
-    hipStream_t copy_stream = nullptr, add_stream = nullptr;
-    hipEvent_t copied[2] = { nullptr, nullptr }, added[2] = { nullptr, nullptr };
-    chk(hipMalloc(&stage[0], bytes), "hipMalloc");
-    if (n_src > 1) chk(hipMalloc(&stage[1], bytes), "hipMalloc");
-    chk(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
-    chk(hipStreamCreateWithFlags(&add_stream, hipStreamNonBlocking), "hipStreamCreate");
-    for (int k = 0; k < 2; k++) { chk(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming), "hipEventCreate"); chk(hipEventCreateWithFlags(&added[k], hipEventDisableTiming), "hipEventCreate"); }
-    // whatever wrote the buffers (renders on the null streams of their devices) must be done before they are read or added to
+    // whatever wrote the buffers (renders on the streams of their devices) must be done before they are read or added to
     for (int i = 0; i < n_src && rc == RT_OK; i++) {
-        if (!src_dev[i]) { rc = fail(RT_EINVAL, "a source buffer is NULL"); break; }
         chk(hipSetDevice(src_device[i]), "hipSetDevice");
         chk(hipDeviceSynchronize(), "hipDeviceSynchronize (source)");
     }
     chk(hipSetDevice(dst_device), "hipSetDevice");
     chk(hipDeviceSynchronize(), "hipDeviceSynchronize (destination)");
+    ReduceCtx& c = g_reduce[dst_device];
+    const int lanes = std::min(n_src, kReduceLanes);
+    if (rc == RT_OK) rc = reduce_prepare(c, lanes, bytes);
+    if (rc == RT_OK) for (int i = 0; i < n_src; i++) enable_peer(dst_device, src_device[i]);
     const unsigned blocks = (unsigned) ((n_values + 255) / 256);
+    // every source's copy is queued on its lane's stream at once (lanes run together); the additions follow on one stream in source
+    // order, each waiting for its copy; a lane's buffer is reused by source i + kReduceLanes once source i has been added
     for (int i = 0; i < n_src && rc == RT_OK; i++) {
-        const int b = i & 1;
-        if (i >= 2) chk(hipStreamWaitEvent(copy_stream, added[b], 0), "hipStreamWaitEvent");          // the buffer's previous content has been consumed
-        chk(hipMemcpyPeerAsync(stage[b], dst_device, src_dev[i], src_device[i], bytes, copy_stream), "hipMemcpyPeerAsync");
-        chk(hipEventRecord(copied[b], copy_stream), "hipEventRecord");
-        chk(hipStreamWaitEvent(add_stream, copied[b], 0), "hipStreamWaitEvent");
+        const int b = i % lanes;
+        if (i >= lanes) chk(hipStreamWaitEvent(c.copy_stream[b], c.added[b], 0), "hipStreamWaitEvent");
+        chk(hipMemcpyPeerAsync(c.stage[b], dst_device, src_dev[i], src_device[i], bytes, c.copy_stream[b]), "hipMemcpyPeerAsync");
+        chk(hipEventRecord(c.copied[b], c.copy_stream[b]), "hipEventRecord");
+        chk(hipStreamWaitEvent(c.add_stream, c.copied[b], 0), "hipStreamWaitEvent");
         if (rc != RT_OK) break;
-        if (accum_is_fp64) hipLaunchKernelGGL(add_kernel<double>, dim3(blocks), dim3(256), 0, add_stream, static_cast<double*>(dst_dev), static_cast<const double*>(stage[b]), n_values);
-        else hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, add_stream, static_cast<float*>(dst_dev), static_cast<const float*>(stage[b]), n_values);
+        if (accum_is_fp64) hipLaunchKernelGGL(add_kernel<double>, dim3(blocks), dim3(256), 0, c.add_stream, static_cast<double*>(dst_dev), static_cast<const double*>(c.stage[b]), n_values);
+        else hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, c.add_stream, static_cast<float*>(dst_dev), static_cast<const float*>(c.stage[b]), n_values);
         chk(hipGetLastError(), "add kernel launch");
-        chk(hipEventRecord(added[b], add_stream), "hipEventRecord");
+        chk(hipEventRecord(c.added[b], c.add_stream), "hipEventRecord");
     }
-    chk(hipStreamSynchronize(add_stream), "hipStreamSynchronize");
-    chk(hipStreamSynchronize(copy_stream), "hipStreamSynchronize");
-    for (int k = 0; k < 2; k++) { if (copied[k]) (void) hipEventDestroy(copied[k]); if (added[k]) (void) hipEventDestroy(added[k]); if (stage[k]) (void) hipFree(stage[k]); }
-    if (copy_stream) (void) hipStreamDestroy(copy_stream);
-    if (add_stream) (void) hipStreamDestroy(add_stream);
+    // also on failure: nothing of this call may still be in flight when the caller frees its buffers
+    if (c.add_stream) chk(hipStreamSynchronize(c.add_stream), "hipStreamSynchronize");
+    for (hipStream_t st : c.copy_stream) chk(hipStreamSynchronize(st), "hipStreamSynchronize");
     if (current != dst_device) (void) hipSetDevice(current);
     return rc;
+}
+
+int rt_frame_reduce_release(void)
+{
+    int current = -1;
+    HIP_TRY(hipGetDevice(&current));
+    std::lock_guard<std::mutex> lock(g_reduce_mutex);
+    for (int d = 0; d < kMaxDevices; d++) {
+        if (g_reduce[d].stage.empty() && !g_reduce[d].add_stream) continue;
+        if (hipSetDevice(d) == hipSuccess) reduce_release(g_reduce[d]);
+    }
+    (void) hipSetDevice(current);
+    return RT_OK;
 }
 
 int rt_resolve(const void* accum_dev, int accum_is_fp64, size_t n_pixels, int spp, uint8_t* rgb_dev, void* stream)

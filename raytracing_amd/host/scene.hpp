@@ -104,7 +104,7 @@ public:
             for (int i = 0; i < n_dev; i++) {
                 rt_render_stats st{};
                 check(rt_render_wait(dev[i], &st));
-                total.rays += st.rays; total.rejected_samples += st.rejected_samples;
+                total.rays += st.rays; total.rejected_samples += st.rejected_samples; total.untraced_rays += st.untraced_rays;
                 if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;
             }
             if (stats_out) *stats_out = total;

@@ -15,7 +15,7 @@ FLAG_ACCUMULATE, FLAG_EARLY_EXIT, FLAG_COUNT_TESTS, FLAG_DEBUG_RAY_COUNTS, FLAG_
 PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 NOALLOC_MAX_RAYS = 32768
 
-EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_wait", "rt_device_count", "rt_device_set", "rt_frame_reduce", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
+EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_wait", "rt_render_kernel_name", "rt_device_count", "rt_device_set", "rt_frame_reduce", "rt_frame_reduce_release", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
            "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
            "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
@@ -48,7 +48,8 @@ class RenderParams(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rejected_samples", C.c_uint64), ("kernel_ms", C.c_double), ("box_tests", C.c_uint64), ("leaf_tests", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64), ("phase_ticks", C.c_uint64 * 4), ("zero_direction_rays", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_leaf_steps", C.c_uint64), ("wave_bounces", C.c_uint64), ("phase_ticks", C.c_uint64 * 4), ("zero_direction_rays", C.c_uint64),
+                ("untraced_rays", C.c_uint64)]
 
 
 _lib = None
@@ -67,6 +68,7 @@ def load_library():
         L.rt_scene_destroy.argtypes = [C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(RenderStats)]
         L.rt_render_wait.argtypes = [C.c_void_p, C.POINTER(RenderStats)]
+        L.rt_render_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         L.rt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.rt_device_set.argtypes = [C.c_int]
         L.rt_frame_reduce.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_size_t]
@@ -205,13 +207,20 @@ class Scene:
         _check(load_library().rt_render(self.h, C.byref(p), C.c_void_p(accum_ptr), C.byref(st) if want_stats else None))
         return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms), box_tests=int(st.box_tests),
                     leaf_tests=int(st.leaf_tests), wave_node_steps=int(st.wave_node_steps), wave_leaf_steps=int(st.wave_leaf_steps),
-                    wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks], zero_direction_rays=int(st.zero_direction_rays)) if want_stats else None
+                    wave_bounces=int(st.wave_bounces), phase_ticks=[int(x) for x in st.phase_ticks], zero_direction_rays=int(st.zero_direction_rays),
+                    untraced_rays=int(st.untraced_rays)) if want_stats else None
+
+    def kernel_name(self, mode, flags=0):
+        """name of the kernel a render of this scene launches, as rocprofv3 lists it (rt_render_kernel_name)"""
+        buf = C.create_string_buffer(256)
+        _check(load_library().rt_render_kernel_name(self.h, mode, flags, buf, 256))
+        return buf.value.decode()
 
     def render_wait(self):
         """collect a render started with want_stats=False (rt_render_wait)"""
         st = RenderStats()
         _check(load_library().rt_render_wait(self.h, C.byref(st)))
-        return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms))
+        return dict(rays=int(st.rays), rejected=int(st.rejected_samples), kernel_ms=float(st.kernel_ms), untraced_rays=int(st.untraced_rays))
 
     def render_to_host(self, width, height, spp_begin, spp_end, max_depth, mode=MODE_FAST_FP32, seed=0, flags=0, y_begin=0, y_end=None):
         """Convenience for tests: render into a fresh device buffer, return (sums[h,w,3], rgb[h,w,3], stats).  With a row
@@ -284,6 +293,11 @@ def frame_reduce(dst_ptr, dst_device, src_ptrs, src_devices, is_fp64, n_values):
     ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(p) for p in src_ptrs])
     devs = (C.c_int * max(n, 1))(*src_devices)
     _check(load_library().rt_frame_reduce(C.c_void_p(dst_ptr), dst_device, ptrs, devs, n, int(is_fp64), n_values))
+
+
+def frame_reduce_release():
+    """free the staging buffers rt_frame_reduce keeps between calls"""
+    _check(load_library().rt_frame_reduce_release())
 
 
 def device_count():

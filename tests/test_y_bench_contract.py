@@ -43,6 +43,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields(R):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and "spp" in c["sample"]
     assert d["value"] > 3 * c["value"], "the GPU path is the one that was timed (a frame this small is launch-bound: the ratio says nothing else)"
     assert d["image"]["same_streams"]["rays_gpu"] == d["image"]["same_streams"]["rays_cpu"]
+    # the headline counts rays that walked the tree; the reference's count (every trace() call, zero-direction phong rays included) rides along
+    assert d["config"]["rays_per_step"] <= d["config"]["reference_rays_per_step"] and d["value"] <= d["value_reference_ray_count"]
+    share = 1.0 - d["config"]["rays_per_step"] / d["config"]["reference_rays_per_step"]
+    assert abs(share - d["config"]["zero_direction_ray_share"]) < 0.02, "in a scene of triangles alone every zero-direction ray is finished without a traversal"
+    assert r["kernel"].startswith("rt::render_wave_kernel<double, false, ")
     assert d["fp32_mode"]["dtype"] == "f32" and d["fp32_mode"]["value"] > 0
 
 
@@ -71,6 +76,33 @@ def test_bench_under_the_launcher_with_two_ranks(R):
     assert two["n_gpus"] == 2 and single["n_gpus"] == 1 and two["steps"] == 2 and two["value"] > 0
     assert two["config"]["rays_per_step"] == single["config"]["rays_per_step"], "streams are keyed by the global sample index: same frame for any N"
     assert "gloo" in two["config"]["parallelism"] or "2" in two["config"]["parallelism"]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(R):
+    """Plain `python bench.py --gpus 2`, no launcher and no WORLD_SIZE: bench.py starts the two ranks itself (a child
+    `python -m torch.distributed.run`, before the parent has touched the GPU), relays rank 0's one JSON line and returns the
+    launcher's exit code.  Rehearsed with gloo ranks sharing the one device.  Ranks other than 0 take the scene from rank 0's
+    binary cache (rt_scene_desc_save / load) instead of building it again: same frame, same ray count."""
+    import json
+    import sys
+    small = ["--width", "160", "--height", "90", "--spp", "8", "--steps", "2", "--warmup", "1", "--mesh-level", "3", "--no-cpu", "--image-width", "0", "--no-fp32"]
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    two = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, capture_output=True, text=True, timeout=200, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["value"] > 0
+    assert two["config"]["rays_per_step"] == single["config"]["rays_per_step"] and two["config"]["reference_rays_per_step"] == single["config"]["reference_rays_per_step"]
+    assert two["config"]["n_primitives"] == single["config"]["n_primitives"]
+    # a launcher that fails must fail bench.py too: three ranks cannot split... they can; an unknown flag cannot be parsed by any rank
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-such-flag"], capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode != 0 and not bad.stdout.strip()
 
 
 def test_bench_rccl_branch_with_a_group_of_one(R):
