@@ -84,8 +84,11 @@ struct alignas(16) BNode {
 // kernel uses the whole dword as the origin, exponent bits included, and the builder accounts for them; lo[a] / hi[a]: byte k = child
 // k's low / high plane in steps from the origin (lo rounded down, hi up, after padding by the fp32 decode error, so the decoded boxes
 // contain the real ones).  lo <= hi byte-wise, so which plane a ray meets first follows from the sign of its direction alone: the
-// near planes are lo[a] for a ray going up the axis, else hi[a] -- no min / max per plane pair.  child[k]: child code as in BNode, or
-// RT_BVH_SENTINEL for an unused slot; n: children in use (2..4; 1 for a single-leaf tree).
+// near planes are lo[a] for a ray going up the axis, else hi[a] -- no min / max per plane pair.  child[k]: child code as in BNode; an
+// unused slot names the dummy leaf (rtcore.hip: one record no ray can hit), so a visit tests nothing per child but its box.
+// Slot order is visiting order: the builder sorts the children by their centres along one axis; a ray going up that axis takes the
+// slots forwards, a ray going down it backwards (no sort by entry distance in the kernel).  n: that axis times 0x01010101 (a v_perm_b32
+// selector, rt_wave.h node_step); pad[0]: children in use (2..4; 1 for a single-leaf tree).
 struct alignas(16) WNode {
     uint32_t o[3];
     uint32_t lo[3];
@@ -1079,6 +1082,12 @@ struct RenderArgs {
     // rt_queue.h (decoupled traversal / shading): slots per wave (0: the rt_wave.h kernel), pools allocated, lanes that must wait before a
     // hand-off is run, known hits from which a starved wave shades a partial pass
     uint32_t q_slots, q_pools, q_handoff_min, q_shade_starved;
+    // rt_wave.h, cost-ordered launch: a scheduling unit is a super-tile (xcd_tiles) or a tile.  unit_order (or null): launch slot ->
+    // unit, the units sorted by the rays they cost in an earlier render of the same frame geometry, dearest first, so that the
+    // workgroups still running when the queue has emptied are the cheap ones (the launch's tail).  unit_cost (or null): this launch
+    // adds every workgroup's ray count to its unit's entry
+    const uint32_t* unit_order;
+    uint32_t* unit_cost;
 };
 
 // ------------------------------------------------------------------ render kernel

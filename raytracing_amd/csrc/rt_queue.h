@@ -127,7 +127,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
 
     int slot = -1;                                      // the pool slot this lane traverses for; -1: idle
     Ray<R> ray;
-    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
+    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.sg = 0u; tv.sel[0] = tv.sel[1] = tv.sel[2] = 0x03020100u;
     Closest<R> best;
     if constexpr (sizeof(R) == 8) best.t = R(0);
 

@@ -59,8 +59,10 @@ struct Trav {                 // per-lane traversal state, kept across phases
     float slack;              // absolute slack of the slab comparison (rounding of o/d)
     float closest;            // far bound of the slab tests: the closest hit so far (R = double: rounded from Closest<double>::t)
     int32_t hit, cur;
+    // wide nodes (node_step): byte selectors for v_perm_b32 over a node's { high-plane word, low-plane word } pair
+    uint32_t sel[3];          // per axis: 0x07060504 (the near planes are the high ones: the ray goes down the axis) or 0x03020100
+    uint32_t sg;              // byte a = 0x03 if the ray goes down axis a, else 0: XORed into a selector it reverses the order of the four children
     uint32_t sp;              // LDS byte address of this lane's top stack entry (level * 1024 + lane * 4): push / pop are one add
-    uint32_t rot;             // quantised nodes: per axis (byte a) 16 if the ray goes down the axis, else 0
 };
 // the closest hit's distance in the precision of the results.  R = float: Trav::closest is that value already.
 template <typename R> struct Closest { R t; };
@@ -86,7 +88,8 @@ template <typename R> __device__ inline void trav_begin(Trav& t, Closest<R>& c, 
     else t.idir = vec3<float>(__builtin_amdgcn_rcpf(safe((float) r.d.x)), __builtin_amdgcn_rcpf(safe((float) r.d.y)), __builtin_amdgcn_rcpf(safe((float) r.d.z)));
     t.noid = vec3<float>(-(float) r.o.x * t.idir.x, -(float) r.o.y * t.idir.y, -(float) r.o.z * t.idir.z);
     t.slack = cull_slack<R>::k * fmaxf(fmaxf(fabsf(t.noid.x), fabsf(t.noid.y)), fabsf(t.noid.z));
-    t.rot = (t.idir.x < 0.f ? 16u : 0u) | (t.idir.y < 0.f ? 16u << 8 : 0u) | (t.idir.z < 0.f ? 16u << 16 : 0u);
+    t.sel[0] = t.idir.x < 0.f ? 0x07060504u : 0x03020100u; t.sel[1] = t.idir.y < 0.f ? 0x07060504u : 0x03020100u; t.sel[2] = t.idir.z < 0.f ? 0x07060504u : 0x03020100u;
+    t.sg = (t.idir.x < 0.f ? 0x03u : 0u) | (t.idir.y < 0.f ? 0x0300u : 0u) | (t.idir.z < 0.f ? 0x030000u : 0u);
     set_closest(t, c, rt_inf<R>());
     t.hit = -1;
     t.cur = 0;
@@ -111,16 +114,18 @@ template <typename T> __device__ inline const T* at32(const T* base, uint32_t by
     return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
 }
 
-// all four children of a wide node (rt_device.h WNode): the near planes are the low bytes for a ray going up the axis, else the high ones
-template <typename R> __device__ inline void slab_wide(const WNode& n, const Trav& t, float t_min, float tn[4], bool h[4])
+// All four children of a wide node (rt_device.h WNode), in VISITING order: child k of the results is slot k for a ray going up the node's
+// sort axis, slot 3 - k for one going down it (`flip` = 0x03030303 then, else 0).  One v_perm_b32 per plane word does both jobs -- it picks
+// the near (far) planes' word by the sign of the ray's direction and puts its four bytes in visiting order.
+template <typename R> __device__ inline void slab_wide(const WNode& n, const Trav& t, uint32_t flip, float t_min, bool h[4])
 {
     float nr[3][4], fr[3][4];
     const float idir[3] = { t.idir.x, t.idir.y, t.idir.z }, noid[3] = { t.noid.x, t.noid.y, t.noid.z };
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float A = ldexpf(idir[a], (int) (int8_t) (n.o[a] & 0xffu)), B = fmaf(__uint_as_float(n.o[a]), idir[a], noid[a]);
-        const bool down = ((t.rot >> (8 * a)) & 16u) != 0u;
-        const uint32_t qn = down ? n.hi[a] : n.lo[a], qf = down ? n.lo[a] : n.hi[a];
+        const uint32_t sel = t.sel[a] ^ flip;
+        const uint32_t qn = __builtin_amdgcn_perm(n.hi[a], n.lo[a], sel), qf = __builtin_amdgcn_perm(n.lo[a], n.hi[a], sel);
         // two planes per instruction (v_pk_fma_f32): 12 VALU instructions fewer per visit, mesh workload -0.8 % time
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 A2 = { A, A }, B2 = { B, B };
@@ -134,8 +139,7 @@ template <typename R> __device__ inline void slab_wide(const WNode& n, const Tra
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const float near = fmaxf(fmaxf(nr[0][k], nr[1][k]), fmaxf(nr[2][k], t_min)), far = fminf(fminf(fr[0][k], fr[1][k]), fminf(fr[2][k], t.closest));
-        tn[k] = near;
-        h[k] = near <= fmaf(far, cull_slack<R>::rel, t.slack) && n.child[k] != RT_BVH_SENTINEL;
+        h[k] = near <= fmaf(far, cull_slack<R>::rel, t.slack);
     }
 }
 
@@ -147,25 +151,23 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
     if constexpr (kQuant) {
         RT_ASM_MARK("; wide node_step begin");
         const WNode n = *at32(sc.wnodes, (uint32_t) tv.cur * (uint32_t) sizeof(WNode));
-        float t4[4]; bool h4[4];
-        slab_wide<R>(n, tv, t_min, t4, h4);
+        // Slot order is visiting order (rt_bvh_build.h widen_node: children sorted along one axis, whose byte of tv.sg the selector n.n
+        // broadcasts): forwards for a ray going up that axis, backwards for one going down.  No entry distances are compared: the
+        // five-exchange sort this replaces was 29 of the visit's 122 vector instructions, for 1..3 % fewer visits
+        // (tools/trav_policy_sim.cpp).  The reversal is folded into the byte selectors of the plane words, so the hit flags come out
+        // of the box tests in visiting order; the four child codes take a select each.
+        const uint32_t flip = __builtin_amdgcn_perm(tv.sg, tv.sg, n.n);
+        bool h[4];
+        slab_wide<R>(n, tv, flip, t_min, h);
         if (kCount && first_active_lane()) vs.w_node++;
-        if (kCount) vs.n_box += n.n;
-        int32_t c4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { c4[k] = n.child[k]; if (!h4[k]) t4[k] = __builtin_inff(); }
-        // nearest first: a five-exchange network over (distance, child); a child that was missed sorts last
-        auto order = [&](int i, int j) {
-            const bool sw = t4[j] < t4[i];
-            const float ti = sw ? t4[j] : t4[i], tj = sw ? t4[i] : t4[j];
-            const int32_t ci = sw ? c4[j] : c4[i], cj = sw ? c4[i] : c4[j];
-            t4[i] = ti; t4[j] = tj; c4[i] = ci; c4[j] = cj;
-        };
-        order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
-        if (t4[3] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[3]; }
-        if (t4[2] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[2]; }
-        if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
-        if (t4[0] < __builtin_inff()) tv.cur = c4[0];
+        if (kCount) vs.n_box += n.pad[0];
+        const bool rev = flip != 0u;
+        const int32_t c0 = rev ? n.child[3] : n.child[0], c1 = rev ? n.child[2] : n.child[1], c2 = rev ? n.child[1] : n.child[2], c3 = rev ? n.child[0] : n.child[3];
+        // the children behind the first one hit wait on the stack, the last to be visited pushed first
+        if (h[3] && (h[0] || h[1] || h[2])) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c3; }
+        if (h[2] && (h[0] || h[1])) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c2; }
+        if (h[1] && h[0]) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c1; }
+        if (h[0] || h[1] || h[2] || h[3]) tv.cur = h[0] ? c0 : h[1] ? c1 : h[2] ? c2 : c3;
         else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
         RT_ASM_MARK("; wide node_step end");
     }
@@ -199,15 +201,22 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     // eighth tile of a strip across the image
     const int tiles_x = (a.width + 15) >> 4;
     int tile_x, tile_y;
+    uint32_t unit;                                                            // the scheduling unit this workgroup belongs to (RenderArgs::unit_order)
     if (a.xcd_tiles) {
         const int tiles_y = (a.y_end - a.y_begin + 15) >> 4;
-        const int stx = (tiles_x + 7) >> 3;
-        const int s = (int) (blockIdx.x >> 3), super = (s >> 6) * 8 + (int) (blockIdx.x & 7u), within = s & 63;
+        const int stx = (tiles_x + 7) >> 3, sty = (tiles_y + 7) >> 3;
+        const int s = (int) (blockIdx.x >> 3), slot = (s >> 6) * 8 + (int) (blockIdx.x & 7u), within = s & 63;
+        if (slot >= stx * sty) return;                                        // grid padding (whole workgroup, before any barrier)
+        const int super = a.unit_order ? (int) a.unit_order[slot] : slot;
         const int sy = super / stx, sx = super - sy * stx;
         tile_x = sx * 8 + (within & 7); tile_y = sy * 8 + (within >> 3);
         if (tile_x >= tiles_x || tile_y >= tiles_y) return;                   // whole workgroup, before any barrier
+        unit = (uint32_t) super;
     }
-    else { tile_x = (int) (blockIdx.x % (unsigned) tiles_x); tile_y = (int) (blockIdx.x / (unsigned) tiles_x); }
+    else {
+        unit = a.unit_order ? a.unit_order[blockIdx.x] : blockIdx.x;
+        tile_x = (int) (unit % (unsigned) tiles_x); tile_y = (int) (unit / (unsigned) tiles_x);
+    }
     extern __shared__ __align__(16) unsigned char smem[];
     // entry `level` of this lane: LDS address of smem + level * 1024 + lane * 4, kept as a 32-bit LDS address so that a push or
     // pop is one add and a ds instruction (no base to add, no generic pointer)
@@ -217,7 +226,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     R* tile_sum = reinterpret_cast<R*>(smem + a.lds_tile_offset);
     unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
     tile_sum[threadIdx.x * 3] = R(0); tile_sum[threadIdx.x * 3 + 1] = R(0); tile_sum[threadIdx.x * 3 + 2] = R(0);
-    if (threadIdx.x == 0) *item_counter = 0u;
+    if (threadIdx.x == 0) { item_counter[0] = 0u; item_counter[1] = 0u; }     // [1]: waves of this workgroup that have finished
     stack_at(stack_base) = (uint32_t) RT_BVH_SENTINEL;
     __syncthreads();
 
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     Ray<R> ray;
     vec3<R> beta;          // the path's throughput.  No running radiance: a material that emits does not scatter (material.hpp:156-159,
                            // :215), so the only non-zero term of L = sum beta_i * emission_i is the last hit's
-    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.rot = 0u;
+    Trav tv; tv.cur = RT_BVH_SENTINEL; tv.sp = stack_base; tv.hit = -1; tv.closest = 0.f; tv.slack = 0.f; tv.sg = 0u; tv.sel[0] = tv.sel[1] = tv.sel[2] = 0x03020100u;
     Closest<R> best;
     if constexpr (sizeof(R) == 8) best.t = R(0);
 
@@ -414,14 +423,45 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
         lap(3);
     }
 
-    __syncthreads();
-    int j, i;
-    pixel_of((int) threadIdx.x, j, i);
-    if (j < a.width && i < a.y_end) {
-        R* out = accum + ((size_t) i * a.width + j) * 3;
-        const R sx = tile_sum[threadIdx.x * 3], sy = tile_sum[threadIdx.x * 3 + 1], sz = tile_sum[threadIdx.x * 3 + 2];
-        if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sx; out[1] += sy; out[2] += sz; }
-        else { out[0] = sx; out[1] = sy; out[2] = sz; }
+    if constexpr (!class_is_obj(kFull)) {
+        // A wave whose tile has no sample left for it ENDS here, without waiting for the others: its registers and its wave slot are free
+        // at once, and as soon as four slots of the CU are (and LDS allows) the next workgroup starts -- instead of a tile's last long
+        // paths holding four wave slots until the slowest of them is done.  The tile's sums are written by whichever wave finishes last.
+        // Measured at 4K, fp64: random spheres -0.6 % (16 spp) / -1.3 % (128 spp) time, deep bounce -2.3 % / -1.6 %.  Not for the OBJ-loader
+        // variants: their traversal stack fills the LDS three workgroups share, so a freed wave slot lets nobody in, and the single-wave
+        // write-out cost the mesh 0.6 % at every sample count.
+        const bool last_wave = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");               // this wave's additions to the tile sums come before its count
+            unsigned int n = 0;
+            if (lane == 0) n = atomicAdd(item_counter + 1, 1u);
+            n = (unsigned int) __builtin_amdgcn_readfirstlane((int) n);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            return n == 3u;
+        }();
+        if (last_wave) {
+#pragma unroll 1
+            for (int slot = lane; slot < 256; slot += 64) {
+                int j, i;
+                pixel_of(slot, j, i);
+                if (j < a.width && i < a.y_end) {
+                    R* out = accum + ((size_t) i * a.width + j) * 3;
+                    const R sx = tile_sum[slot * 3], sy = tile_sum[slot * 3 + 1], sz = tile_sum[slot * 3 + 2];
+                    if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sx; out[1] += sy; out[2] += sz; }
+                    else { out[0] = sx; out[1] = sy; out[2] = sz; }
+                }
+            }
+        }
+    }
+    else {
+        __syncthreads();
+        int j, i;
+        pixel_of((int) threadIdx.x, j, i);
+        if (j < a.width && i < a.y_end) {
+            R* out = accum + ((size_t) i * a.width + j) * 3;
+            const R sx = tile_sum[threadIdx.x * 3], sy = tile_sum[threadIdx.x * 3 + 1], sz = tile_sum[threadIdx.x * 3 + 2];
+            if (a.flags & RT_FLAG_ACCUMULATE) { out[0] += sx; out[1] += sy; out[2] += sz; }
+            else { out[0] = sx; out[1] = sy; out[2] = sz; }
+        }
     }
 
     // wave-level reduction of the counters, one atomic pair per wave
@@ -429,6 +469,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
         atomicAdd(&counters[0], wave_rays);
         if (wave_rejected) atomicAdd(&counters[1], wave_rejected);
         if (wave_untraced) atomicAdd(&counters[15], wave_untraced);
+        if (a.unit_cost) atomicAdd(&a.unit_cost[unit], (unsigned int) (wave_rays >> 6) + 1u);      // in units of 64 rays: a super-tile of a long frame stays below 2^32
     }
     if (kCount) {
         unsigned long long nb = vs.n_box, nl = vs.n_leaf, wn = vs.w_node, wl = vs.w_leaf, wb = vs.w_bounce, nz = vs.n_zero;

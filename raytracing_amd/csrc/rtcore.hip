@@ -122,6 +122,13 @@ struct rt_scene {
     uint32_t trav_keep = 96, node_keep = 128, regen_min = 16;
     uint32_t xcd_tiles = 0;                   // super-tiles dealt to the XCDs (rt_wave.h): on when tree + records exceed one XCD's L2; RT_XCD_TILES overrides
     uint32_t quantised = 0;                   // fast mode walks the quantised four-wide nodes (RT_QNODES overrides)   // rt_wave.h phase thresholds (RT_TRAV_KEEP / RT_NODE_KEEP / RT_REGEN_MIN override)
+    // cost-ordered launch of the wave kernel (rt_device.h RenderArgs::unit_order): per scheduling unit (super-tile or tile) the rays of the
+    // first render of a frame geometry, then the units sorted by them, dearest first; kept for every later render of that geometry
+    uint32_t* unit_cost = nullptr; uint32_t* unit_order = nullptr;
+    uint32_t n_units = 0;
+    int32_t order_key[5] = { 0, 0, 0, 0, 0 };  // width, height, y_begin, y_end, xcd_tiles the buffers were made for
+    int order_state = 0;                      // 0: nothing yet, 1: the outstanding (or last waited) render is collecting costs, 2: unit_order is valid
+    bool tile_order = true;                   // RT_TILE_ORDER=0: launch in image order (A/B)
     uint32_t stack_pad = 0;                   // RT_STACK_PAD: stack levels reserved beyond what the tree needs (test hook for the > 48 KiB LDS launches)
     size_t lds_limit = 0;   // reference-order program is read from global memory unless RT_LDS_LIMIT allows staging it in LDS
 };
@@ -318,6 +325,16 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
     }
 }
 
+// the record behind the wide nodes' unused child slots: a triangle of zero area, which no ray hits (polygon.hpp:95-97: a = 0); material and
+// id 0 exist in every scene, so even a NaN ray that "hits" it (the reference's range test passes NaN) reads valid memory
+template <typename R> rt::Prim<R> dummy_record()
+{
+    rt::Prim<R> p;
+    std::memset(&p, 0, sizeof p);
+    p.kf = RT_PRIM_TRIANGLE; p.mat = 0; p.id = 0;
+    return p;
+}
+
 template <typename R> int build_fast_tree(const rt_scene_desc*, const Flat&, const std::vector<rt::Prim<R>>&, DeviceScene<R>& out, const DeviceScene<float>* tree);
 // fp64 (RT_MODE_FAST_FP64): the fp32 scene's tree -- nodes only cull, in fp32, for both precisions -- with the fp64 primitive
 // records in its leaf order.  Node arrays stay owned by the fp32 scene.
@@ -325,10 +342,11 @@ template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const
 {
     out.view.bnodes = nullptr; out.view.wnodes = nullptr; out.view.wide_stack = 0; out.view.fprims = nullptr; out.view.n_bnodes = 0; out.view.bvh_depth = 0;
     if (!tree || !tree->view.bnodes) return RT_OK;
-    if (tree->leaf_order.size() * sizeof(rt::Prim<double>) >= (1ull << 32))
+    if ((tree->leaf_order.size() + 1) * sizeof(rt::Prim<double>) >= (1ull << 32))
         return fail(RT_EUNSUPPORTED, "fast-mode fp64 record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");
-    std::vector<rt::Prim<double>> ordered(tree->leaf_order.size());
-    for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree->leaf_order[i]];
+    std::vector<rt::Prim<double>> ordered(tree->leaf_order.size() + 1);
+    for (size_t i = 0; i < tree->leaf_order.size(); i++) ordered[i] = prims[tree->leaf_order[i]];
+    ordered.back() = dummy_record<double>();
     int rc;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
     out.view.bnodes = tree->view.bnodes; out.view.wnodes = tree->view.wnodes; out.view.wide_stack = tree->view.wide_stack; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
@@ -365,7 +383,7 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     rtb::Tree tree = rtb::Builder(items, leaf_max, c_prim, depth_limit, bins).build();
     if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] fast tree: %zu nodes, depth %d (limit %d), leaf_max %d, c_prim %.2f\n", tree.nodes.size(), tree.depth, depth_limit, leaf_max, c_prim);
     if (tree.depth + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode tree deeper than the traversal stack");
-    if (tree.nodes.size() * sizeof(rt::BNode) >= (1ull << 32) || tree.order.size() * sizeof(rt::Prim<float>) >= (1ull << 32))
+    if (tree.nodes.size() * sizeof(rt::BNode) >= (1ull << 32) || (tree.order.size() + 1) * sizeof(rt::Prim<float>) >= (1ull << 32) || tree.order.size() >= (1u << 28))
         return fail(RT_EUNSUPPORTED, "fast-mode tree or record array beyond 4 GiB (the kernel addresses records by 32-bit byte offsets)");
     std::vector<rt::BNode> nodes(tree.nodes.size());
     for (size_t i = 0; i < nodes.size(); i++) {
@@ -385,6 +403,7 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     int budget = 35;
     if (const char* e = std::getenv("RT_WIDE_STACK")) budget = std::max(1, std::atoi(e));
     const rtb::WideTree wt = rtb::widen(tree, budget);
+    const int32_t dummy_leaf = ~(int32_t) ((uint32_t) tree.order.size() * 8u);      // leaf of one record: the one after the last real record
     std::vector<rt::WNode> wn(wt.nodes.size());
     for (size_t i = 0; i < wn.size(); i++) {
         const rtb::WideNode& w = wt.nodes[i];
@@ -394,13 +413,18 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
             for (int k = 0; k < w.n; k++) { lo[k] = (double) down(w.box[k].lo[a]) - pad; hi[k] = (double) up(w.box[k].hi[a]) + pad; }
             rtb::quantise_axis_wide(lo, hi, w.n, wn[i].o[a], wn[i].lo[a], wn[i].hi[a]);
         }
-        for (int k = 0; k < 4; k++) wn[i].child[k] = k < w.n ? w.child[k] : RT_BVH_SENTINEL;
-        wn[i].n = (uint32_t) w.n;
+        // an unused slot names the dummy leaf (one record that no ray can hit, appended to the record arrays below): its box decodes
+        // inside out (lo 255, hi 0) and is missed, but should rounding ever let a ray into it, the ray tests a triangle of zero area
+        // and walks on -- so the visit needs no validity test per child
+        for (int k = 0; k < 4; k++) wn[i].child[k] = k < w.n ? w.child[k] : dummy_leaf;
+        wn[i].n = (uint32_t) w.axis * 0x01010101u;      // as a v_perm_b32 selector: byte `axis` of its first operand, four times
+        wn[i].pad[0] = (uint32_t) w.n;
     }
     if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree: %zu nodes of 64 B, stack need %d entries\n", wn.size(), wt.stack_need);
     if (wt.stack_need + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode wide tree needs a deeper traversal stack than RT_BVH_STACK_MAX");
-    std::vector<rt::Prim<float>> ordered(tree.order.size());
-    for (size_t i = 0; i < ordered.size(); i++) ordered[i] = prims[tree.order[i]];
+    std::vector<rt::Prim<float>> ordered(tree.order.size() + 1);
+    for (size_t i = 0; i < tree.order.size(); i++) ordered[i] = prims[tree.order[i]];
+    ordered.back() = dummy_record<float>();
     out.leaf_order.assign(tree.order.begin(), tree.order.end());
     int rc;
     if ((rc = upload(out.owned, nodes, &out.view.bnodes))) return rc;
@@ -606,6 +630,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     if (const char* env = std::getenv("RT_TRAV_KEEP")) s->trav_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_NODE_KEEP")) s->node_keep = (uint32_t) std::min(256, std::max(1, std::atoi(env)));
     if (const char* env = std::getenv("RT_REGEN_MIN")) s->regen_min = (uint32_t) std::min(64, std::max(1, std::atoi(env)));
+    if (const char* env = std::getenv("RT_TILE_ORDER")) s->tile_order = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_STACK_PAD")) s->stack_pad = (uint32_t) std::min(RT_BVH_STACK_MAX, std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("RT_QUEUE")) s->queue = std::atoi(env) != 0;
     if (const char* env = std::getenv("RT_Q_SLOTS")) s->q_slots = (uint32_t) std::min(RT_Q_SLOTS_MAX, std::max(64, std::atoi(env)));
@@ -623,6 +648,8 @@ int rt_scene_destroy(rt_scene* s)
     if (s->wf.host_pinned) (void) hipHostFree(s->wf.host_pinned);
     for (int k = 0; k < 2; k++) { if (s->q_pools[k]) (void) hipFree(s->q_pools[k]); if (s->q_locks[k]) (void) hipFree(s->q_locks[k]); }
     if (s->counters) (void) hipFree(s->counters);
+    if (s->unit_cost) (void) hipFree(s->unit_cost);
+    if (s->unit_order) (void) hipFree(s->unit_order);
     if (s->ev0) (void) hipEventDestroy(s->ev0);
     if (s->ev1) (void) hipEventDestroy(s->ev1);
     delete s;
@@ -689,6 +716,37 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
         if (e != hipSuccess) { (void) hipFree(pools); return fail(RT_EHIP, std::string("hipMalloc of the decoupled kernel's pool locks: ") + hipGetErrorString(e)); }
         s->q_pools[qk] = pools; s->q_locks[qk] = locks;
     }
+    // cost-ordered launch (wave kernel only): the first render of a frame geometry counts rays per scheduling unit, later ones launch the
+    // units dearest first.  Scheduling only: every tile still adds up its own samples, so sums and counts do not change.
+    // Measured at 4K, fp64 (tools/drain_ab.py, profiles/r03_*_drain_ab_*): random spheres -4 % time at 16 and 128 spp, Cornell box -6 %, the
+    // deep-bounce scene -11 % (16 spp) and -18 % (128 spp): its dear tiles -- 200-bounce paths through glass -- are few, and in image
+    // order the last of them ran alone.  Not under the XCD super-tile order (scenes that outgrow an L2): there image order keeps the chip
+    // on one compact region of the image and of the tree; sorted by cost the 1.3 M-triangle mesh ran 3-4 % slower at 16, 128 and 512 spp
+    // alike, and moving only its cheap super-tiles to the end changed nothing (its fixed ~4 ms per launch is every workgroup's own
+    // drain, not the launch's tail).
+    if (s->tile_order && !s->xcd_tiles && fast_mode && !decoupled && !(p->flags & (RT_FLAG_LEGACY_LOOP | RT_FLAG_WAVEFRONT)) && p->y_end > p->y_begin) {
+        const int tiles_x = (p->width + 15) / 16, tiles_y = (p->y_end - p->y_begin + 15) / 16;
+        const uint32_t units = s->xcd_tiles ? (uint32_t) (((tiles_x + 7) / 8) * ((tiles_y + 7) / 8)) : (uint32_t) (tiles_x * tiles_y);
+        const int32_t key[5] = { p->width, p->height, p->y_begin, p->y_end, (int32_t) s->xcd_tiles };
+        if (std::memcmp(key, s->order_key, sizeof key) != 0 || !s->unit_cost) {
+            if (s->unit_cost) (void) hipFree(s->unit_cost);
+            if (s->unit_order) (void) hipFree(s->unit_order);
+            s->unit_cost = s->unit_order = nullptr; s->order_state = 0; s->n_units = 0;
+            std::memset(s->order_key, 0, sizeof s->order_key);
+            uint32_t* cost = nullptr; uint32_t* order = nullptr;
+            HIP_TRY(hipMalloc((void**) &cost, (size_t) units * sizeof(uint32_t)));
+            const hipError_t e = hipMalloc((void**) &order, (size_t) units * sizeof(uint32_t));
+            if (e != hipSuccess) { (void) hipFree(cost); return fail(RT_EHIP, std::string("hipMalloc of the launch order: ") + hipGetErrorString(e)); }
+            s->unit_cost = cost; s->unit_order = order; s->n_units = units;
+            std::memcpy(s->order_key, key, sizeof key);
+        }
+        if (s->order_state == 2) a.unit_order = s->unit_order;
+        else {
+            HIP_TRY(hipMemsetAsync(s->unit_cost, 0, (size_t) units * sizeof(uint32_t), st));
+            a.unit_cost = s->unit_cost;
+            s->order_state = 1;
+        }
+    }
     HIP_TRY(hipMemsetAsync(s->counters, 0, 16 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
     if (decoupled) {
@@ -750,6 +808,14 @@ int rt_render_wait(rt_scene* s, rt_render_stats* stats)
     auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
     chk(hipEventSynchronize(s->ev1), "hipEventSynchronize");
     s->pending = false;
+    if (rc == RT_OK && s->order_state == 1 && s->unit_cost && s->n_units) {       // the render just waited for counted rays per unit: sort once
+        std::vector<uint32_t> cost(s->n_units), order(s->n_units);
+        chk(hipMemcpy(cost.data(), s->unit_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "launch-order costs");
+        for (uint32_t i = 0; i < s->n_units; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        chk(hipMemcpy(s->unit_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "launch order");
+        s->order_state = rc == RT_OK ? 2 : 0;
+    }
     if (rc == RT_OK && stats) {
         float ms = 0;
         chk(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");

@@ -64,7 +64,7 @@ int main(int argc, char** argv)
     const int budget = argc > 5 ? std::atoi(argv[5]) : 35;
     const rtb::WideTree w = rtb::widen(t, budget);
     std::vector<int> w_prim(n, 0), w_node(w.nodes.size(), 0);
-    long w_bad_box = 0, w_shared = 0, w_bad_n = 0, w_full = 0;
+    long w_bad_box = 0, w_shared = 0, w_bad_n = 0, w_full = 0, w_unsorted = 0;
     int w_worst_stack = 0;
     std::function<rtb::Box(int32_t, int)> wwalk = [&](int32_t c, int on_stack) {
         rtb::Box b;
@@ -77,6 +77,18 @@ int main(int argc, char** argv)
         const rtb::WideNode& nd = w.nodes[c];
         if (nd.n < 1 || nd.n > 4 || (nd.n == 1 && n != 1)) w_bad_n++;
         w_full += nd.n == 4;
+        // slot order is visiting order: the children's centres ascend along the node's sort axis, which is the axis of their widest spread
+        if (nd.axis < 0 || nd.axis > 2) w_unsorted++;
+        else {
+            for (int k = 1; k < nd.n; k++) if (nd.box[k].lo[nd.axis] + nd.box[k].hi[nd.axis] < nd.box[k - 1].lo[nd.axis] + nd.box[k - 1].hi[nd.axis]) w_unsorted++;
+            double spread[3];
+            for (int a = 0; a < 3; a++) {
+                double lo = 1e300, hi = -1e300;
+                for (int k = 0; k < nd.n; k++) { const double c = nd.box[k].lo[a] + nd.box[k].hi[a]; lo = std::min(lo, c); hi = std::max(hi, c); }
+                spread[a] = hi - lo;
+            }
+            for (int a = 0; a < 3; a++) if (spread[a] > spread[nd.axis]) w_unsorted++;
+        }
         if (on_stack + nd.n - 1 > w_worst_stack) w_worst_stack = on_stack + nd.n - 1;
         for (int k = 0; k < nd.n; k++) {
             const rtb::Box sub = wwalk(nd.child[k], on_stack + nd.n - 1);      // worst case: every sibling still waits on the stack
@@ -89,7 +101,7 @@ int main(int argc, char** argv)
     long w_missing = 0, w_repeated = 0, w_unreachable = 0;
     for (int v : w_prim) { w_missing += v == 0; w_repeated += v > 1; }
     for (int v : w_node) w_unreachable += v == 0;
-    std::printf(" w_nodes=%zu w_full=%ld w_stack=%d w_worst_stack=%d w_missing=%ld w_repeated=%ld w_unreachable=%ld w_shared=%ld w_bad_box=%ld w_bad_n=%ld\n",
-                w.nodes.size(), w_full, w.stack_need, w_worst_stack, w_missing, w_repeated, w_unreachable, w_shared, w_bad_box, w_bad_n);
+    std::printf(" w_nodes=%zu w_full=%ld w_stack=%d w_worst_stack=%d w_missing=%ld w_repeated=%ld w_unreachable=%ld w_shared=%ld w_bad_box=%ld w_bad_n=%ld w_unsorted=%ld\n",
+                w.nodes.size(), w_full, w.stack_need, w_worst_stack, w_missing, w_repeated, w_unreachable, w_shared, w_bad_box, w_bad_n, w_unsorted);
     return 0;
 }

@@ -48,6 +48,7 @@ def test_wide_tree_is_the_same_partition_within_its_stack_budget(harness, n, lim
     r = run(harness, n, limit, 64, 4, budget)
     assert r["w_missing"] == 0 and r["w_repeated"] == 0 and r["w_unreachable"] == 0 and r["w_shared"] == 0
     assert r["w_bad_box"] == 0 and r["w_bad_n"] == 0
+    assert r["w_unsorted"] == 0, "slot order is visiting order: children ascend along the node's sort axis (rt_wave.h node_step compares no distances)"
     assert r["w_worst_stack"] <= r["w_stack"]
     assert r["w_stack"] <= max(budget, r["depth"] - 1), r
     if n >= 1000 and budget >= 35:

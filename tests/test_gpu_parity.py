@@ -617,6 +617,35 @@ def test_xcd_super_tile_order_renders_the_same_pixels(R, monkeypatch, w, h, rows
     assert not a[0][:rows[0]].any() and not a[0][rows[1]:].any() and a[0][rows[0]:rows[1], :, 0].min() >= 1
 
 
+@pytest.mark.parametrize("xcd", ["0", "1"])
+@pytest.mark.parametrize("w,h,rows", [(200, 140, (0, 140)), (129, 17, (0, 17)), (272, 260, (37, 203))])
+def test_cost_ordered_launch_renders_the_same_pixels(R, monkeypatch, w, h, rows, xcd):
+    """The wave kernel's cost-ordered launch (rtcore.hip: the first render of a frame geometry counts rays per scheduling unit -- a tile, or
+    a super-tile under the XCD order --, rt_render_wait sorts the units, every later render launches them dearest first so that the
+    launch's tail is made of cheap tiles) is a permutation of the tiles as well: the first render of a scene (image order, collecting),
+    the second (ordered), a render of other rows (new geometry: collecting again) and the first geometry once more give the same
+    per-pixel ray counts as a scene with RT_TILE_ORDER=0, rows outside the range stay untouched, and fp64 sums of the ordered render
+    equal the unordered one's to the rounding of the tile additions."""
+    from raytracing_amd.host_scenes import HostScene
+    monkeypatch.setenv("RT_XCD_TILES", xcd)
+    monkeypatch.setenv("RT_TILE_ORDER", "0")
+    hs = HostScene.random_spheres(w, h, 1)
+    plain = hs.upload()
+    want, _, st_want = plain.render_to_host(w, h, 0, 4, 50, R.MODE_FAST_FP32, seed=9, flags=R.FLAG_DEBUG_RAY_COUNTS, y_begin=rows[0], y_end=rows[1])
+    want64, _, _ = plain.render_to_host(w, h, 0, 4, 50, R.MODE_FAST_FP64, seed=9, y_begin=rows[0], y_end=rows[1])
+    monkeypatch.setenv("RT_TILE_ORDER", "1")
+    sc = hs.upload()
+    for step in range(4):
+        y0, y1 = rows if step != 2 else (rows[0], max(rows[0] + 1, (rows[0] + rows[1]) // 2))
+        got, _, st = sc.render_to_host(w, h, 0, 4, 50, R.MODE_FAST_FP32, seed=9, flags=R.FLAG_DEBUG_RAY_COUNTS, y_begin=y0, y_end=y1)
+        assert np.array_equal(got[y0:y1], want[y0:y1]), step
+        assert not got[:y0].any() and not got[y1:].any()
+        assert st["rays"] == int(got[..., 0].sum()) and (step == 2 or st["rays"] == st_want["rays"])
+    got64, _, _ = sc.render_to_host(w, h, 0, 4, 50, R.MODE_FAST_FP64, seed=9, y_begin=rows[0], y_end=rows[1])
+    assert np.allclose(got64, want64, rtol=1e-13, atol=1e-13 * float(np.abs(want64).max()))
+    sc.destroy(); plain.destroy(); hs.free()
+
+
 @pytest.mark.parametrize("which", ["random_spheres", "obj"])
 def test_decoupled_kernel_traces_the_same_paths(R, golden_dir, which):
     """RT_FLAG_QUEUE (rt_queue.h: per-wave path pools, lanes hand finished traversals to full-width shade passes -- the loser of a
