@@ -117,7 +117,7 @@ template <typename T> __device__ inline const T* at32(const T* base, uint32_t by
 // All four children of a wide node (rt_device.h WNode), in VISITING order: child k of the results is slot k for a ray going up the node's
 // sort axis, slot 3 - k for one going down it (`flip` = 0x03030303 then, else 0).  One v_perm_b32 per plane word does both jobs -- it picks
 // the near (far) planes' word by the sign of the ray's direction and puts its four bytes in visiting order.
-template <typename R> __device__ inline void slab_wide(const WNode& n, const Trav& t, uint32_t flip, float t_min, bool h[4])
+template <typename R> __device__ inline void slab_wide(const WNode& n, const Trav& t, uint32_t flip, float t_min, bool h[4], float* tn = nullptr)
 {
     float nr[3][4], fr[3][4];
     const float idir[3] = { t.idir.x, t.idir.y, t.idir.z }, noid[3] = { t.noid.x, t.noid.y, t.noid.z };
@@ -140,6 +140,7 @@ template <typename R> __device__ inline void slab_wide(const WNode& n, const Tra
     for (int k = 0; k < 4; k++) {
         const float near = fmaxf(fmaxf(nr[0][k], nr[1][k]), fmaxf(nr[2][k], t_min)), far = fminf(fminf(fr[0][k], fr[1][k]), fminf(fr[2][k], t.closest));
         h[k] = near <= fmaf(far, cull_slack<R>::rel, t.slack);
+        if (tn) tn[k] = near;                 // (RT_SORTED_VISIT only)
     }
 }
 
@@ -156,6 +157,27 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         // five-exchange sort this replaces was 29 of the visit's 122 vector instructions, for 1..3 % fewer visits
         // (tools/trav_policy_sim.cpp).  The reversal is folded into the byte selectors of the plane words, so the hit flags come out
         // of the box tests in visiting order; the four child codes take a select each.
+#ifdef RT_SORTED_VISIT      // A/B only (make EXTRA=-DRT_SORTED_VISIT): round 2's visit -- hit children sorted by entry distance with a five-exchange network
+        float t4[4]; bool h4[4];
+        slab_wide<R>(n, tv, 0u, t_min, h4, t4);
+        if (kCount && first_active_lane()) vs.w_node++;
+        if (kCount) vs.n_box += n.pad[0];
+        int32_t c4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c4[k] = n.child[k]; if (!h4[k]) t4[k] = __builtin_inff(); }
+        auto order = [&](int i, int j) {
+            const bool sw = t4[j] < t4[i];
+            const float ti = sw ? t4[j] : t4[i], tj = sw ? t4[i] : t4[j];
+            const int32_t ci = sw ? c4[j] : c4[i], cj = sw ? c4[i] : c4[j];
+            t4[i] = ti; t4[j] = tj; c4[i] = ci; c4[j] = cj;
+        };
+        order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
+        if (t4[3] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[3]; }
+        if (t4[2] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[2]; }
+        if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
+        if (t4[0] < __builtin_inff()) tv.cur = c4[0];
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+#else
         const uint32_t flip = __builtin_amdgcn_perm(tv.sg, tv.sg, n.n);
         bool h[4];
         slab_wide<R>(n, tv, flip, t_min, h);
@@ -169,6 +191,7 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         if (h[1] && h[0]) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c1; }
         if (h[0] || h[1] || h[2] || h[3]) tv.cur = h[0] ? c0 : h[1] ? c1 : h[2] ? c2 : c3;
         else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+#endif
         RT_ASM_MARK("; wide node_step end");
     }
     else {

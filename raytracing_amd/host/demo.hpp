@@ -11,6 +11,8 @@
 #include "transform.hpp"
 #include "util.hpp"
 
+#include <vector>
+
 inline group random_scene()
 {
     group grp;
@@ -70,50 +72,124 @@ inline group deep_bounce_scene()
     return group(new bvh(grp, 0, 1));
 }
 
-// reference: src/cpp/demo.hpp:94-143, statement for statement (the image path of :132 does not exist anywhere: the texture
-// fails to load and is cyan, texture.hpp:97-99)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The reference's two remaining demo scenes as DATA: what they hold is the reference's (src/cpp/demo.hpp:63-91 cornell_box, :94-143
+// all_feature_test -- the numbers have to be its numbers, the bit-exact tree fixtures tests/golden/cornell.npz and features.npz pin
+// them), how they are put together is this file's: a palette, a list of parts, one assembler.  A part that draws random numbers
+// (the field of boxes, the cloud of spheres) draws them when the assembler reaches it, so rand() is consumed in list order -- the
+// reference's order -- and the trees come out node for node.
+namespace demo_parts {
+
+struct paint { char kind; double r, g, b, value; };      // 'L' lambertian | 'M' metal (value: roughness) | 'G' dielectric (value: index) | 'E' emissive
+                                                          // | 'I' lambertian over an image file that does not exist (texture.hpp:97-99: cyan)
+struct part {
+    enum what_t { rect_xy, rect_xz, rect_yz, ball, moving_ball, block, medium_in_ball, ball_with_medium, box_field, ball_cloud } what;
+    double n[8];          // rect: a0 a1 b0 b1 k | ball: centre, radius | moving_ball: centre, radius, travel in x | block: size xyz, turn (degrees), place xyz
+                          // medium_in_ball / ball_with_medium: centre, radius, density, fog colour | box_field: cells, pitch, origin, lowest and highest top
+                          // ball_cloud: count, extent, radius, turn (degrees), place xyz
+    int paint;            // palette row (media: the boundary sphere's glass)
+    bool flipped;
+};
+
+inline material* mix(const paint& p)
+{
+    switch (p.kind) {
+    case 'L': return new lambertian(vec3d(p.r, p.g, p.b));
+    case 'M': return new metal(vec3d(p.r, p.g, p.b), p.value);
+    case 'G': return new dielectric(p.value);
+    case 'E': return new emissive(vec3d(p.r, p.g, p.b));
+    default:  return new lambertian(new image("C:/Users/Cronix/Pictures/image.jpg"));
+    }
+}
+
+// palette rows are mixed once and shared by every part that names them (the reference shares its material pointers the same way)
+inline group assemble(const paint* palette, int n_paints, const part* parts, int n_parts)
+{
+    std::vector<material*> pot(n_paints, nullptr);
+    auto colour = [&](int i) { if (!pot[i]) pot[i] = mix(palette[i]); return pot[i]; };
+    group out;
+    for (int i = 0; i < n_parts; i++) {
+        const part& p = parts[i];
+        const double* n = p.n;
+        object* made = nullptr;
+        switch (p.what) {
+        case part::rect_xy: made = new planexy(n[0], n[1], n[2], n[3], n[4], colour(p.paint)); break;
+        case part::rect_xz: made = new planexz(n[0], n[1], n[2], n[3], n[4], colour(p.paint)); break;
+        case part::rect_yz: made = new planeyz(n[0], n[1], n[2], n[3], n[4], colour(p.paint)); break;
+        case part::ball: made = new sphere(vec3d(n[0], n[1], n[2]), n[3], colour(p.paint)); break;
+        case part::moving_ball: made = new msphere(vec3d(n[0], n[1], n[2]), vec3d(n[0], n[1], n[2]) + vec3d(n[4], 0, 0), 0, 1, n[3], colour(p.paint)); break;
+        case part::block:
+            made = new translate(new rotatey(new box(vec3d(0, 0, 0), vec3d(n[0], n[1], n[2]), colour(p.paint)), n[3]), vec3d(n[4], n[5], n[6]));
+            break;
+        case part::medium_in_ball:       // the boundary is not an object of the scene: only the medium inside it is
+            made = new volume(new sphere(vec3d(n[0], n[1], n[2]), n[3], mix(palette[p.paint])), n[4], vec3d(n[5], n[6], n[7]));
+            break;
+        case part::ball_with_medium: {   // a glass ball AND the medium it bounds: two objects over one boundary
+            object* shell = new sphere(vec3d(n[0], n[1], n[2]), n[3], mix(palette[p.paint]));
+            out.add(shell);
+            made = new volume(shell, n[4], vec3d(n[5], n[6], n[7]));
+            break;
+        }
+        case part::box_field: {          // cells x cells boxes standing on y = 0, tops drawn per box, x-major like the reference's loops
+            group field;
+            const int cells = (int) n[0];
+            for (int ix = 0; ix < cells; ix++)
+                for (int iz = 0; iz < cells; iz++) {
+                    const double x = n[2] + ix * n[1], z = n[2] + iz * n[1];
+                    const double top = random_double(n[3], n[4]);
+                    field.add(new box(vec3d(x, 0, z), vec3d(x + n[1], top, z + n[1]), colour(p.paint)));
+                }
+            out.add(field);
+            continue;
+        }
+        case part::ball_cloud: {         // count balls at random places in a cube, under a tree of their own, turned and moved as one
+            group cloud;
+            for (int k = 0; k < (int) n[0]; k++) cloud.add(new sphere(random_vector(0, n[1]), n[2], colour(p.paint)));
+            made = new translate(new rotatey(new bvh(cloud), n[3]), vec3d(n[4], n[5], n[6]));
+            break;
+        }
+        }
+        out.add(p.flipped ? new flip(made) : made);
+    }
+    return out;
+}
+
+// ---- the Cornell box of the reference's main()
+const paint cornell_palette[] = { { 'L', 0.65, 0.05, 0.05, 0 }, { 'L', 0.12, 0.45, 0.15, 0 }, { 'L', 0.75, 0.75, 0.75, 0 }, { 'E', 30, 30, 30, 0 }, { 'M', 1, 1, 1, 0 } };
+const part cornell_parts[] = {
+    { part::rect_yz, { 0, 555, 0, 555, 555 }, 1, false },                      // green wall
+    { part::rect_yz, { 0, 555, 0, 555, 0 }, 0, false },                        // red wall
+    { part::rect_xz, { 0, 555, 0, 555, 0 }, 2, false },                        // floor
+    { part::rect_xz, { 0, 555, 0, 555, 555 }, 2, false },                      // ceiling
+    { part::rect_xy, { 0, 555, 0, 555, 555 }, 2, false },                      // back wall
+    { part::rect_xz, { 213, 343, 227, 332, 554 }, 3, true },                   // the lamp, facing down
+    { part::block, { 165, 330, 165, 15, 265, 0, 295 }, 4, false },             // tall mirror block
+    { part::block, { 165, 165, 165, -18, 130, 0, 65 }, 2, false },             // short white block
+};
+
+// ---- "the next week"'s closing scene as the reference builds it
+const paint feature_palette[] = { { 'L', 0.73, 0.73, 0.73, 0 }, { 'L', 0.48, 0.83, 0.53, 0 }, { 'E', 7, 7, 7, 0 }, { 'L', 0.7, 0.3, 0.1, 0 }, { 'G', 0, 0, 0, 1.5 },
+                                  { 'M', 0.8, 0.8, 0.9, 1 }, { 'I', 0, 0, 0, 0 }, { 'M', 1, 1, 1, 0 } };
+const part feature_parts[] = {
+    { part::box_field, { 20, 100, -1000, 1, 101 }, 1, false },                 // 400 ground boxes, tops between 1 and 101
+    { part::rect_xz, { 123, 423, 147, 412, 554 }, 2, false },                  // the lamp (not flipped: it shines upwards, as in the reference)
+    { part::moving_ball, { 400, 400, 200, 50, 100 }, 3, false },
+    { part::ball, { 260, 150, 45, 50 }, 4, false },                            // glass
+    { part::ball, { 0, 150, 145, 50 }, 5, false },                             // fuzzy metal
+    { part::medium_in_ball, { 0, 0, 0, 5000, 0.0002, 1, 1, 1 }, 4, false },    // haze over everything
+    { part::ball_with_medium, { 360, 150, 145, 70, 0.2, 0.2, 0.4, 0.9 }, 4, false },   // glass ball full of blue fog
+    { part::ball, { 400, 200, 400, 100 }, 6, false },                          // the ball with the picture that is not there
+    { part::ball, { 220, 280, 300, 50 }, 7, false },                           // mirror
+    { part::ball_cloud, { 1000, 165, 10, 15, -100, 270, 395 }, 0, false },
+};
+
+}  // namespace demo_parts
+
+// reference: src/cpp/demo.hpp:94-143 (the image path of :132 exists nowhere: the texture fails to load and is cyan, texture.hpp:97-99)
 inline group all_feature_test()
 {
-    group grp;
-    group ground_boxes;
-    material* white_mat = new lambertian(vec3d(0.73, 0.73, 0.73));
-    material* ground_mat = new lambertian(vec3d(0.48, 0.83, 0.53));
-    material* area_light = new emissive(vec3d(7, 7, 7));
-    for (int i = 0; i < 20; i++) {
-        for (int j = 0; j < 20; j++) {
-            double w = 100;
-            double x0 = -1000 + i * w;
-            double z0 = -1000 + j * w;
-            double y0 = 0;
-            double x1 = x0 + w;
-            double z1 = z0 + w;
-            double y1 = random_double(1, 101);
-            ground_boxes.add(new box(vec3d(x0, y0, z0), vec3d(x1, y1, z1), ground_mat));
-        }
-    }
-    grp.add(ground_boxes);
-    grp.add(new planexz(123, 423, 147, 412, 554, area_light));
-    vec3d center_start = vec3d(400, 400, 200);
-    vec3d center_end = center_start + vec3d(100, 0, 0);
-    material* motion_ball_mat = new lambertian(vec3d(0.7, 0.3, 0.1));
-    grp.add(new msphere(center_start, center_end, 0, 1, 50, motion_ball_mat));
-    grp.add(new sphere(vec3d(260, 150, 45), 50, new dielectric(1.5)));
-    grp.add(new sphere(vec3d(0, 150, 145), 50, new metal(vec3d(0.8, 0.8, 0.9), 1)));
-    object* background = new sphere(vec3d(0, 0, 0), 5000, new dielectric(1.5));
-    grp.add(new volume(background, 0.0002, vec3d(1, 1, 1)));
-    background = new sphere(vec3d(360, 150, 145), 70, new dielectric(1.5));
-    grp.add(background);
-    grp.add(new volume(background, 0.2, vec3d(0.2, 0.4, 0.9)));
-    material* img_mat = new lambertian(new image("C:/Users/Cronix/Pictures/image.jpg"));
-    grp.add(new sphere(vec3d(400, 200, 400), 100, img_mat));
-    grp.add(new sphere(vec3d(220, 280, 300), 50, new metal(vec3d(1, 1, 1), 0)));
-    group vol_boxes;
-    for (int i = 0; i < 1000; i++) {
-        vol_boxes.add(new sphere(random_vector(0, 165), 10, white_mat));
-    }
-    grp.add(new translate(new rotatey(new bvh(vol_boxes), 15), vec3d(-100, 270, 395)));
-    bvh* bvh_grp = new bvh(grp, 0, 1);
-    return group(bvh_grp);
+    group grp = demo_parts::assemble(demo_parts::feature_palette, 8, demo_parts::feature_parts, 10);
+    return group(new bvh(grp, 0, 1));
 }
 
 // the sphere-bounded media of all_feature_test() (reference: src/cpp/demo.hpp:117-134: haze in a radius-5000 sphere, a glass ball
@@ -139,25 +215,5 @@ inline group smoke_scene()
 // the scene of the reference's main() (reference: src/cpp/demo.hpp:63-91)
 inline group cornell_box()
 {
-    group grp;
-    material* red_diffuse = new lambertian(vec3d(0.65, 0.05, 0.05));
-    material* green_diffuse = new lambertian(vec3d(0.12, 0.45, 0.15));
-    material* white_diffuse = new lambertian(vec3d(0.75, 0.75, 0.75));
-    material* area_light = new emissive(vec3d(30, 30, 30));
-    material* mirror = new metal(vec3d(1, 1, 1), 0);
-    grp.add(new planeyz(0, 555, 0, 555, 555, green_diffuse));
-    grp.add(new planeyz(0, 555, 0, 555, 0, red_diffuse));
-    grp.add(new planexz(0, 555, 0, 555, 0, white_diffuse));
-    grp.add(new planexz(0, 555, 0, 555, 555, white_diffuse));
-    grp.add(new planexy(0, 555, 0, 555, 555, white_diffuse));
-    grp.add(new flip(new planexz(213, 343, 227, 332, 554, area_light)));
-    object* box1 = new box(vec3d(0, 0, 0), vec3d(165, 330, 165), mirror);
-    box1 = new rotatey(box1, 15);
-    box1 = new translate(box1, vec3d(265, 0, 295));
-    grp.add(box1);
-    object* box2 = new box(vec3d(0, 0, 0), vec3d(165, 165, 165), white_diffuse);
-    box2 = new rotatey(box2, -18);
-    box2 = new translate(box2, vec3d(130, 0, 65));
-    grp.add(box2);
-    return grp;
+    return demo_parts::assemble(demo_parts::cornell_palette, 5, demo_parts::cornell_parts, 8);
 }

@@ -13,6 +13,9 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/hbm_traffic.json"
 if "--out" in sys.argv:
     args.remove(out_path)
+round_tag = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r03"
+if "--round" in sys.argv:
+    args.remove(round_tag)
 
 
 def counter(db, name, kernel_sub):
@@ -42,6 +45,7 @@ try:
 except (OSError, ValueError):
     table = {}
 table[key] = {"bytes_per_ray": bytes_per_launch / rays, "fetch_KB_per_launch": f_kb, "write_KB_per_launch": w_kb, "rays_per_launch": rays,
-              "spp_profiled": cfg["spp"], "round": "r02", "note": "FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by these memory-side counters"}
+              "spp_profiled": cfg["spp"], "round": round_tag, "ray_count": "traced" if "reference_rays_per_step" in cfg else "reference",
+              "note": "FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by these memory-side counters; bytes_per_ray is per ray that walked the tree"}
 json.dump(table, open(out_path, "w"), indent=1)
 print(key, table[key])
