@@ -261,6 +261,15 @@ int rt_scene_desc_free(rt_scene_desc* desc);
 int rt_checkpoint_save(const char* path, const void* accum_dev, int accum_is_fp64, int32_t width, int32_t height, int32_t spp_done, uint64_t seed);
 int rt_checkpoint_load(const char* path, void* accum_dev, int accum_is_fp64, int32_t width, int32_t height, int32_t* spp_done, uint64_t* seed);
 
+/* Test tooling for the fp64-vs-CPU comparison (tools/first_divergence.py; no counterpart in the reference).  rt_debug_path: the path of ONE
+ * stream (pixel row i, column j, global sample k) through the reference-order walk with the render kernel's own functions -- per segment a row
+ * of 9 doubles: ray origin, direction, time, hit distance (0: miss), primitive id (-1); *n_out = segments traced (rows beyond `cap` are not
+ * stored).  rt_debug_libm: the device library's results for n calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log), so that a
+ * CPU path's libm calls can be replayed on the GPU and compared bit for bit.  Both synchronous, both allocate. */
+int rt_debug_path(rt_scene* scene, int32_t width, int32_t height, int32_t i, int32_t j, int32_t k, uint64_t seed, int32_t max_depth, int32_t flags,
+                  double* rows9_host, int32_t cap, int32_t* n_out_host);
+int rt_debug_libm(const int32_t* op, const double* x, const double* y, int32_t n, double* out_host);
+
 /* n draws of the counter-based stream (seed, pixel, sample), computed on the device (test hook for the RNG) */
 int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host);
 

@@ -35,6 +35,23 @@ static inline v3 smul(double s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }  
 static inline v3 sdiv(v3 a, double s) { return smul(1 / s, a); }                             /* vec3.hpp:121-123 */
 static inline double vdot(v3 a, v3 b) { double r1 = a.x * b.x, r2 = a.y * b.y, r3 = a.z * b.z; return r1 + r2 + r3; } /* :67-72 */
 static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* libm calls of the per-path code go through these, so that orc_debug_libm can list them (operation, arguments, result, and the path
+ * segment during whose shading they were made): tools/first_divergence.py evaluates the same arguments on the GPU and shows where
+ * glibc's and the device library's last bits part.  Logging is off (one predictable branch) except inside orc_debug_libm. */
+static double* g_lm_out = 0; static int g_lm_n = 0, g_lm_cap = 0;
+static int g_lm_segment = 0;
+static inline double lm_log(int op, double x, double y, double r)
+{
+    if (g_lm_out && g_lm_n < g_lm_cap) { double* w = g_lm_out + 5 * g_lm_n++; w[0] = g_lm_segment; w[1] = op; w[2] = x; w[3] = y; w[4] = r; }
+    return r;
+}
+static inline double LM_sin(double x) { return lm_log(1, x, 0, sin(x)); }
+static inline double LM_cos(double x) { return lm_log(2, x, 0, cos(x)); }
+static inline double LM_acos(double x) { return lm_log(3, x, 0, acos(x)); }
+static inline double LM_atan2(double y, double x) { return lm_log(4, y, x, atan2(y, x)); }
+static inline double LM_pow(double x, double y) { return lm_log(5, x, y, pow(x, y)); }
+static inline double LM_log(double x) { return lm_log(6, x, 0, log(x)); }
+
 static inline double vlen(v3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }          /* :25-27 (pow(.,2) folds to x*x) */
 static inline v3 vnorm(v3 a) { double l = vlen(a); if (l == 0) return V(0, 0, 0); return sdiv(a, l); } /* :60-65 */
 static inline double vget(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
@@ -143,8 +160,8 @@ static v3 rnd_cosine(orc_rng* g)                                          /* uti
     double r1 = rnd(g), r2 = rnd(g);
     double z = sqrt(1 - r2);
     double phi = 2 * ORC_PI * r1;
-    double x = cos(phi) * sqrt(r2);
-    double y = sin(phi) * sqrt(r2);
+    double x = LM_cos(phi) * sqrt(r2);
+    double y = LM_sin(phi) * sqrt(r2);
     return V(x, y, z);
 }
 static inline v3 reflect(v3 in, v3 n) { return vsub(in, smul(2 * vdot(in, n), n)); }          /* util.hpp:154-157 */
@@ -237,7 +254,7 @@ static v3 tex_color(const orc_scene* s, int ti, v3 p, v2 uv)
     switch (t->kind) {
     case ORC_TEX_CONSTANT: return V(t->d[0], t->d[1], t->d[2]);             /* texture.hpp:32-35 */
     case ORC_TEX_CHECKER: {                                                 /* texture.hpp:65-74 */
-        double sine = sin(10 * p.x) * sin(10 * p.y) * sin(10 * p.z);
+        double sine = LM_sin(10 * p.x) * LM_sin(10 * p.y) * LM_sin(10 * p.z);
         return tex_color(s, (int) (sine < 0 ? t->d[0] : t->d[1]), p, uv);
     }
     case ORC_TEX_IMAGE: {                                                   /* texture.hpp:95-124 */
@@ -254,7 +271,7 @@ static v3 tex_color(const orc_scene* s, int ti, v3 p, v2 uv)
         const double scale = 1.0 / 255;
         const uint8_t* b = t->pixels + (y * w * ch + x * ch);
         v3 c = smul(scale, V(b[0], b[1], b[2]));
-        if (t->d[3] != 0) return V(pow(c.x, 2.2), pow(c.y, 2.2), pow(c.z, 2.2));
+        if (t->d[3] != 0) return V(LM_pow(c.x, 2.2), LM_pow(c.y, 2.2), LM_pow(c.z, 2.2));
         return c;
     }
     }
@@ -274,7 +291,7 @@ static double reflectance(double cos_theta, double ior)                  /* mate
 {
     double r = (1 - ior) / (1 + ior);
     r = r * r;
-    return r + (1 - r) * pow((1 - cos_theta), 5);
+    return r + (1 - r) * LM_pow((1 - cos_theta), 5);
 }
 
 static v3 cosine_sample(orc_rng* g, v3 normal)                           /* material.hpp:43-52 */
@@ -378,8 +395,8 @@ static double mat_pdf(orc_rng* g, const orc_mat* m, const isect* x, const ray* w
 /* ------------------------------------------------------------------ primitives */
 static v2 sphere_uv(v3 p)                                                /* primitive.hpp:67-74 */
 {
-    double theta = acos(-p.y);
-    double phi = atan2(-p.z, p.x) + ORC_PI;
+    double theta = LM_acos(-p.y);
+    double phi = LM_atan2(-p.z, p.x) + ORC_PI;
     v2 r = { phi / (2 * ORC_PI), theta / ORC_PI };
     return r;
 }
@@ -550,7 +567,7 @@ static int volume_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g)
     if (c1.t < 0) c1.t = 0;
     double ray_length = vlen(r->d);
     double inner_length = (c2.t - c1.t) * ray_length;
-    double intersect_distance = o->g[4] * log(rnd(g));                  /* :373, g[4] = neg_inv_d */
+    double intersect_distance = o->g[4] * LM_log(rnd(g));                  /* :373, g[4] = neg_inv_d */
     if (intersect_distance > inner_length) return 0;
     x->t = c1.t + intersect_distance / ray_length;
     x->pos = ray_at(r, x->t);
@@ -1496,6 +1513,7 @@ static double* g_path_out = 0; static int g_path_n = 0, g_path_cap = 0;   /* orc
 static v3 trace(orc_scene* s, orc_rng* g, const ray* wi, int depth, uint64_t* rays)
 {
     if (depth <= 0) return V(0, 0, 0);
+    if (g_lm_out) g_lm_segment++;                        /* 1-based index of the segment being traced (orc_debug_libm only: nothing is written otherwise) */
     if (g_path_out && g_path_n < g_path_cap) { double* w = g_path_out + 7 * g_path_n++; w[0] = wi->o.x; w[1] = wi->o.y; w[2] = wi->o.z; w[3] = wi->d.x; w[4] = wi->d.y; w[5] = wi->d.z; w[6] = wi->time; }
     isect x; memset(&x, 0, sizeof x);
     (*rays)++;
@@ -1639,6 +1657,23 @@ int orc_debug_path(orc_scene* s, int i, int j, int k, uint64_t seed, int max_dep
     trace(s, &g, &r, max_depth, &n);
     g_path_out = 0;
     return g_path_n;
+}
+
+/* the libm calls of the same path: rows of (segment, operation, x, y, result); segment s = made while tracing / shading the s-th ray of
+ * the path (1-based; 0 = camera), operations: 1 sin, 2 cos, 3 acos, 4 atan2(x = y-argument, y = x-argument), 5 pow, 6 log.  Returns the row count.
+ * Single-threaded use only (test tooling). */
+int orc_debug_libm(orc_scene* s, int i, int j, int k, uint64_t seed, int max_depth, double* rows5, int cap)
+{
+    orc_rng g; memset(&g, 0, sizeof g);
+    counter_seed(&g, seed, (uint32_t) (i * s->width + j), (uint32_t) k);
+    g_lm_out = rows5; g_lm_n = 0; g_lm_cap = cap; g_lm_segment = 0;
+    double x = (double) (j + rnd(&g)) / (s->width - 1);
+    double y = (double) (i + rnd(&g)) / (s->height - 1);
+    ray r = camera_emit(s, &g, x, y);
+    uint64_t n = 0;
+    trace(s, &g, &r, max_depth, &n);
+    g_lm_out = 0;
+    return g_lm_n;
 }
 
 void orc_set_early_exit(orc_scene* s, int on) { s->early_exit = on; }

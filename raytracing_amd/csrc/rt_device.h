@@ -1332,6 +1332,69 @@ __global__ void __launch_bounds__(256) first_hit_kernel(Scene<R> sc, const doubl
 }
 
 
+#ifdef RT_WITH_FIRST_HIT        // (the fp64 translation unit)
+// ------------------------------------------------------------------ debug kernels (test tooling: tools/first_divergence.py)
+// The path of ONE (pixel, sample) stream through the reference-order walk with the render kernel's own functions (render_kernel above,
+// R = double, kTrav = 0), one lane: per segment the ray (origin, direction, time), the distance of its hit (0: a miss) and the
+// primitive (-1).  -ffp-contract=off makes the arithmetic independent of the surrounding code, so these are the rays the frame traced.
+template <typename R>
+__global__ void path_kernel(Scene<R> sc, RenderArgs a, int i, int j, int k, double* __restrict__ rows9, int cap, int* __restrict__ n_out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    Rng g; g.seed(a.seed, (uint32_t) (i * a.width + j), (uint32_t) k);
+    R x = (R(j) + uniform<R>(g)) / R(a.width - 1);
+    R y = (R(i) + uniform<R>(g)) / R(a.height - 1);
+    Ray<R> ray = camera_emit(sc.cam, g, x, y);
+    VisitStats vs;
+    const bool fixed = (a.flags & RT_FLAG_COMPAT_FIXED) != 0;
+    int n = 0;
+    for (int depth = a.max_depth; depth > 0; depth--) {
+        R t = R(0);
+        const int prim = closest_hit<R, 0>(sc.ops, sc.n_ops, sc.prims, sc.side(), ray, t, &vs, &g);
+        if (n < cap) {
+            double* w = rows9 + (size_t) n * 9;
+            w[0] = ray.o.x; w[1] = ray.o.y; w[2] = ray.o.z; w[3] = ray.d.x; w[4] = ray.d.y; w[5] = ray.d.z; w[6] = ray.time; w[7] = prim >= 0 ? (double) t : 0.0; w[8] = prim;
+        }
+        n++;
+        if (prim < 0) break;
+        Hit<R> h;
+        fill_record(sc.prims[prim], sc.side(), ray, t, sc.need_uv != 0, h);
+        const Mat<R>& m = sc.mats[h.mat];
+        const vec3<R> texc = m.tex >= 0 ? tex_color(sc, m.tex, h.pos, h.u, h.v) : vec3<R>();
+        Ray<R> wo; wo.time = R(0);
+        vec3<R> att;
+        bool spec = false;
+        if (!mat_shading(g, m, ray, h, texc, wo, att, spec, fixed)) break;
+        if (!(fixed && spec)) {
+            if (!spec && uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand(sc, g, h.pos); wo.time = ray.time; }
+            const R mpdf = mat_pdf(g, m, h, wo, fixed && !spec);
+            if (fixed && !spec) { const R pdf = R(0.5) * (lights_pdf(sc, h.pos, wo.d) + mpdf); if (!(pdf > R(0)) || !(mpdf > R(0))) break; }
+        }
+        ray = wo;
+    }
+    *n_out = n;
+}
+
+// the device library's results for the libm calls of a path (operations as oracle/rt_oracle.c numbers them: 1 sin, 2 cos, 3 acos,
+// 4 atan2(x, y), 5 pow(x, y), 6 log), through the same rt_* overloads the kernels call
+__global__ void libm_kernel(const int32_t* __restrict__ op, const double* __restrict__ x, const double* __restrict__ y, int n, double* __restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    double r = 0.0;
+    switch (op[idx]) {
+    case 1: r = rt_sin(x[idx]); break;
+    case 2: r = rt_cos(x[idx]); break;
+    case 3: r = rt_acos(x[idx]); break;
+    case 4: r = rt_atan2(x[idx], y[idx]); break;
+    case 5: r = rt_pow(x[idx], y[idx]); break;
+    case 6: r = rt_log(x[idx]); break;
+    default: break;
+    }
+    out[idx] = r;
+}
+#endif
+
 #ifdef RT_WITH_FAST_BVH
 // fast-mode closest hit of explicit rays (test hook): primitive id and t only (defined in the fp32 translation unit only)
 __global__ void __launch_bounds__(256) first_hit_fast_kernel(Scene<float> sc, const double* __restrict__ rays, int n, int32_t* prim, float* t_out)

@@ -257,6 +257,18 @@ hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int
 #endif
 
 #ifdef RT_WITH_FIRST_HIT
+hipError_t launch_debug_path(const Scene<double>& sc, const RenderArgs& a, int i, int j, int k, double* rows9, int cap, int* n_out, hipStream_t s)
+{
+    hipLaunchKernelGGL((path_kernel<double>), dim3(1), dim3(64), 0, s, sc, a, i, j, k, rows9, cap, n_out);
+    return hipGetLastError();
+}
+hipError_t launch_debug_libm(const int32_t* op, const double* x, const double* y, int n, double* out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(libm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, op, x, y, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,
                             uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash, hipStream_t s)
 {

@@ -23,4 +23,8 @@ hipError_t launch_first_hit_tree(const Scene<float>& sc, const double* rays, int
 hipError_t launch_first_hit_fast(const Scene<float>& sc, const double* rays, int n, int32_t* prim, float* t, hipStream_t s);
 hipError_t launch_first_hit(const Scene<double>& sc, const double* rays, int n, int32_t* prim, double* t, int32_t* front,
                             uint32_t* n_box, uint32_t* n_leaf, unsigned long long* hash, hipStream_t s);
+// test tooling (tools/first_divergence.py): one (pixel, sample) path through the reference-order walk, and the device library's results for
+// a list of libm calls.  fp64 translation unit only.
+hipError_t launch_debug_path(const Scene<double>& sc, const RenderArgs& a, int i, int j, int k, double* rows9, int cap, int* n_out, hipStream_t s);
+hipError_t launch_debug_libm(const int32_t* op, const double* x, const double* y, int n, double* out, hipStream_t s);
 }  // namespace rt

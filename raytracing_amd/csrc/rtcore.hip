@@ -1272,6 +1272,48 @@ int rt_checkpoint_load(const char* path, void* accum_dev, int is_fp64, int32_t w
     return RT_OK;
 }
 
+int rt_debug_path(rt_scene* s, int32_t width, int32_t height, int32_t i, int32_t j, int32_t k, uint64_t seed, int32_t max_depth, int32_t flags,
+                  double* rows9_host, int32_t cap, int32_t* n_out_host)
+{
+    if (!s || !rows9_host || !n_out_host || cap <= 0) return fail(RT_EINVAL, "scene, output rows and their capacity are required");
+    if (width < 2 || height < 2 || i < 0 || i >= height || j < 0 || j >= width || k < 0 || max_depth < 0) return fail(RT_EINVAL, "pixel outside the image, or a negative sample index or depth");
+    if (int rc_dev = require_scene_device(s)) return rc_dev;
+    rt::RenderArgs a{};
+    a.width = width; a.height = height; a.max_depth = max_depth; a.flags = flags; a.seed = seed;
+    double* d_rows = nullptr; int* d_n = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipMalloc((void**) &d_rows, (size_t) cap * 9 * sizeof(double)), "hipMalloc");
+    chk(hipMalloc((void**) &d_n, sizeof(int)), "hipMalloc");
+    if (rc == RT_OK) chk(rt::launch_debug_path(s->d64.view, a, i, j, k, d_rows, cap, d_n, nullptr), "path kernel launch");
+    if (rc == RT_OK) chk(hipDeviceSynchronize(), "path kernel");
+    int n = 0;
+    if (rc == RT_OK) chk(hipMemcpy(&n, d_n, sizeof(int), hipMemcpyDeviceToHost), "download");
+    if (rc == RT_OK) chk(hipMemcpy(rows9_host, d_rows, (size_t) std::min(n, cap) * 9 * sizeof(double), hipMemcpyDeviceToHost), "download");
+    *n_out_host = n;
+    (void) hipFree(d_rows); (void) hipFree(d_n);
+    return rc;
+}
+
+int rt_debug_libm(const int32_t* op, const double* x, const double* y, int32_t n, double* out_host)
+{
+    if (n < 0 || (n && (!op || !x || !y || !out_host))) return fail(RT_EINVAL, "n >= 0 and the four arrays are required");
+    if (n == 0) return RT_OK;
+    int32_t* d_op = nullptr; double* d_v = nullptr;
+    int rc = RT_OK;
+    auto chk = [&](hipError_t err, const char* what) { if (err != hipSuccess && rc == RT_OK) rc = fail(RT_EHIP, std::string(what) + ": " + hipGetErrorString(err)); };
+    chk(hipMalloc((void**) &d_op, (size_t) n * 4), "hipMalloc");
+    chk(hipMalloc((void**) &d_v, (size_t) n * 3 * 8), "hipMalloc");
+    if (rc == RT_OK) chk(hipMemcpy(d_op, op, (size_t) n * 4, hipMemcpyHostToDevice), "upload");
+    if (rc == RT_OK) chk(hipMemcpy(d_v, x, (size_t) n * 8, hipMemcpyHostToDevice), "upload");
+    if (rc == RT_OK) chk(hipMemcpy(d_v + n, y, (size_t) n * 8, hipMemcpyHostToDevice), "upload");
+    if (rc == RT_OK) chk(rt::launch_debug_libm(d_op, d_v, d_v + n, n, d_v + 2 * (size_t) n, nullptr), "libm kernel launch");
+    if (rc == RT_OK) chk(hipDeviceSynchronize(), "libm kernel");
+    if (rc == RT_OK) chk(hipMemcpy(out_host, d_v + 2 * (size_t) n, (size_t) n * 8, hipMemcpyDeviceToHost), "download");
+    (void) hipFree(d_op); (void) hipFree(d_v);
+    return rc;
+}
+
 int rt_debug_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out_host)
 {
     if (n <= 0 || !out_host) return fail(RT_EINVAL, "n > 0 and out_host are required");

@@ -115,6 +115,41 @@ rth_scene* rth_build_cornell(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// The Cornell room with instances in place of its blocks and no medium anywhere: a turned and moved cloud of spheres under a tree of its
+// own (the wrapping all_feature_test() gives its cloud), a metal sphere that is only moved and a glass sphere that is only turned
+// (transforms around single leaves).  The cloud is sparse and diffuse on purpose: 200 balls of radius 12, a third of them fuzzy metal, gave 4 % of
+// the pixels another ray count in fp32 than in fp64 -- as many as the same balls placed in world space without any instance: grazes among
+// small spheres, not a defect; 40 diffuse balls of radius 25 give 1.3 %.
+// Not in the reference: a test scene for the instanced kernel variants, whose other scene --
+// all_feature_test() -- carries media, and a medium's draws follow the visit order, so its per-pixel ray counts cannot be compared
+// between trees.
+rth_scene* rth_build_instanced(int width, int height, unsigned seed)
+{
+    try {
+        const unsigned omit = seed >> 8;        // test hook: bit 0 leaves out the cloud, bit 1 the moved sphere, bit 2 the turned sphere
+        srand(seed & 0xffu);
+        camera cam = camera(vec3d(278, 278, -800), vec3d(278, 278, 0), vec3d(0, 1, 0), 40, 1, 0, 1, 0, 1);
+        scene scn(width, height);
+        material* white = new lambertian(vec3d(0.75, 0.75, 0.75));
+        scn.add_object(new planeyz(0, 555, 0, 555, 555, new lambertian(vec3d(0.12, 0.45, 0.15))));
+        scn.add_object(new planeyz(0, 555, 0, 555, 0, new lambertian(vec3d(0.65, 0.05, 0.05))));
+        scn.add_object(new planexz(0, 555, 0, 555, 0, white));
+        scn.add_object(new planexz(0, 555, 0, 555, 555, white));
+        scn.add_object(new planexy(0, 555, 0, 555, 555, white));
+        scn.add_object(new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30)))));
+        group cloud;
+        for (int k = 0; k < 40; k++) cloud.add(new sphere(random_vector(0, 165), 25, white));
+        if (!(omit & 1u)) scn.add_object(new translate(new rotatey(new bvh(cloud), 15), vec3d(265, 0, 295)));
+        if (!(omit & 2u)) scn.add_object(new translate(new sphere(vec3d(0, 0, 0), 60, new metal(vec3d(0.9, 0.7, 0.5), 0)), vec3d(150, 60, 120)));
+        if (!(omit & 4u)) scn.add_object(new rotatey(new sphere(vec3d(120, 250, 150), 50, new dielectric(1.5)), 30));
+        scn.add_light(new flip(new planexz(213, 343, 227, 332, 554, new emissive(vec3d(30, 30, 30)))));
+        scn.set_camera(cam);
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
 // all_feature_test() (demo.hpp) under the light and camera of oracle/ref_harness.cpp build_features
 rth_scene* rth_build_features(int width, int height, unsigned seed)
 {

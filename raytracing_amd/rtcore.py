@@ -16,7 +16,7 @@ PRIM_STRIDE, MAT_STRIDE, TEX_STRIDE = 24, 16, 8
 NOALLOC_MAX_RAYS = 32768
 
 EXPORTS = ["rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_wait", "rt_render_kernel_name", "rt_device_count", "rt_device_set", "rt_frame_reduce", "rt_frame_reduce_release", "rt_resolve", "rt_first_hit", "rt_first_hit_noalloc", "rt_first_hit_fast", "rt_first_hit_tree", "rt_buffer_alloc", "rt_buffer_free",
-           "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_last_error", "rt_version",
+           "rt_buffer_download", "rt_buffer_upload", "rt_debug_rng", "rt_debug_path", "rt_debug_libm", "rt_last_error", "rt_version",
            "rt_scene_desc_save", "rt_scene_desc_load", "rt_scene_desc_free", "rt_checkpoint_save", "rt_checkpoint_load"]
 
 
@@ -83,6 +83,9 @@ def load_library():
         L.rt_buffer_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_buffer_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_debug_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+        L.rt_debug_path.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                    C.POINTER(C.c_int32)]
+        L.rt_debug_libm.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double)]
         L.rt_scene_desc_save.argtypes = [C.POINTER(SceneDesc), C.c_char_p]
         L.rt_scene_desc_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(SceneDesc))]
         L.rt_scene_desc_free.argtypes = [C.POINTER(SceneDesc)]
@@ -216,6 +219,13 @@ class Scene:
         _check(load_library().rt_render_kernel_name(self.h, mode, flags, buf, 256))
         return buf.value.decode()
 
+    def debug_path(self, width, height, i, j, k, seed, max_depth, flags=0):
+        """segments of one (pixel, sample) path in the fp64 reference mode (rt_debug_path): rows of ray origin, direction, time, hit distance, primitive"""
+        out = np.zeros((max_depth + 1, 9))
+        n = C.c_int32()
+        _check(load_library().rt_debug_path(self.h, width, height, i, j, k, seed, max_depth, flags, _ptr(out, C.c_double), len(out), C.byref(n)))
+        return out[:min(n.value, len(out))]
+
     def render_wait(self):
         """collect a render started with want_stats=False (rt_render_wait)"""
         st = RenderStats()
@@ -308,6 +318,14 @@ def device_count():
 
 def resolve(accum_ptr, is_fp64, n_pixels, spp, rgb_ptr, stream=None):
     _check(load_library().rt_resolve(C.c_void_p(accum_ptr), int(is_fp64), n_pixels, spp, C.c_void_p(rgb_ptr), C.c_void_p(stream) if stream else None))
+
+
+def debug_libm(op, x, y):
+    """the device library's results for libm calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log): rt_debug_libm"""
+    op = np.ascontiguousarray(op, dtype=np.int32); x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(len(op))
+    _check(load_library().rt_debug_libm(_ptr(op, C.c_int32), _ptr(x, C.c_double), _ptr(y, C.c_double), len(op), _ptr(out, C.c_double)))
+    return out
 
 
 def debug_rng(seed, pixel, sample, n):

@@ -218,6 +218,12 @@ class Scene:
         n = lib().orc_debug_path(self.h, i, j, k, C.c_uint64(seed), max_depth, _p(out, C.c_double), len(out))
         return out[:n]
 
+    def debug_libm(self, i, j, k, seed, max_depth, cap=4096):
+        """libm calls of one (pixel, sample) path: rows (segment, op, x, y, result); op 1 sin 2 cos 3 acos 4 atan2 5 pow 6 log"""
+        out = np.zeros((cap, 5))
+        n = lib().orc_debug_libm(self.h, i, j, k, C.c_uint64(seed), max_depth, _p(out, C.c_double), cap)
+        return out[:n]
+
     def set_size(self, width, height):
         """another image size over the same scene and camera fields (keep the aspect ratio)"""
         lib().orc_set_size(self.h, int(width), int(height))

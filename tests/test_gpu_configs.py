@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from divergence import assert_same_streams
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,8 +94,7 @@ def test_config3_soup_with_png_textures_through_the_host_loader(R, tmp_path):
     for name, mode in (("reference", R.MODE_REFERENCE_FP64), ("fast64", R.MODE_FAST_FP64)):
         got, rgb, st = sc.render_to_host(w, h, 0, spp, depth, mode, seed=7)
         frames[name] = got
-        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-        assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, (name, float((rel.max(axis=2) > 1e-9).mean()))
+        assert_same_streams(R, osc, sc, got, want, w, h, spp, 7, depth)
         assert abs(st["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 8 and abs(st["rejected"] - int(cnt[1])) <= 0.002 * int(cnt[1]) + 8, (name, st, cnt)
         assert float((np.abs(rgb.astype(int) - want_rgb.astype(int)) > 1).mean()) <= 0.005
     assert float((np.abs(frames["fast64"] - frames["reference"]) / np.maximum(np.abs(frames["reference"]), 1e-3)).max()) <= 1e-13
@@ -142,8 +142,7 @@ def test_soup_with_jpeg_textures_through_the_host_loader(R, tmp_path, golden_dir
     assert (want.sum(axis=2) > 0).mean() > 0.15, "the frame is lit and shows the soup"
     sc = hs.upload()
     got, rgb, st = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=3)
-    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-    assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, float((rel.max(axis=2) > 1e-9).mean())
+    assert_same_streams(R, osc, sc, got, want, w, h, spp, 3, depth)
     assert abs(st["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 8
     got32, rgb32, st32 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=3)
     assert rel_rmse(got32.astype(np.float64), want) <= 0.05, rel_rmse(got32.astype(np.float64), want)
@@ -176,8 +175,7 @@ def test_config2_mesh_at_tree_depths_the_bench_runs(R, tmp_path, monkeypatch, le
     want, want_rgb, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=13, n_threads=8)
     sc = hs.upload()
     got, rgb, st = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP64, seed=13)
-    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-    assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, float((rel.max(axis=2) > 1e-9).mean())
+    assert_same_streams(R, osc, sc, got, want, w, h, spp, 13, depth)
     assert abs(st["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 8, (st["rays"], int(cnt[0]))
     assert float((rgb != want_rgb).mean()) <= 0.005, float((rgb != want_rgb).mean())
     got32, rgb32, st32 = sc.render_to_host(w, h, 0, spp, depth, R.MODE_FAST_FP32, seed=13)
@@ -321,8 +319,21 @@ def _full_size_frame_properties(R, hs, mode_bar_fp32_rays, depth=50):
     one = sc.render(part_buf.ptr, w, h, 0, 1, depth, R.MODE_FAST_FP64, seed=5)
     got = part_buf.download(np.float64, (h, w, 3))
     rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-    assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, float((rel.max(axis=2) > 1e-9).mean())
-    assert abs(one["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]), (one["rays"], int(cnt[0]))
+    off = np.argwhere(rel.max(axis=2) > 1e-9)
+    assert len(off) <= 1e-5 * w * h, len(off) / float(w * h)       # measured: 0, 0 and 2 of the 8.3 M pixels on the three 4K scenes
+    assert abs(one["rays"] - int(cnt[0])) <= 0.0002 * int(cnt[0]), (one["rays"], int(cnt[0]))
+    # ... and every pixel that does differ (up to 300 of them, taken evenly over the frame) must be EXPLAINED: its two paths replayed, the first
+    # differing ray found, and a libm call of the segment before it shown to come back with other last bits from the device library
+    # (tests/divergence.py).  A pixel that differs for any other reason fails here, however rare.
+    from divergence import explain_pixel
+    unexplained = []
+    for i, j in off[::max(1, len(off) // 300)]:
+        e = explain_pixel(R, osc, sc, w, h, int(i), int(j), 1, 5, depth)
+        if not e["explained"]:
+            unexplained.append((int(i), int(j), e))
+    assert not unexplained, (len(off), unexplained[:3])
+    print(f"[full-size oracle comparison] {len(off)} of {w * h} pixels differ beyond 1e-9 relative ({len(off) / float(w * h):.2e}); "
+          f"{min(len(off), 300)} replayed, all explained by a libm result of other last bits; rays gpu {one['rays']} cpu {int(cnt[0])}")
     osc.free()
 
     f32_buf = R.DeviceBuffer(n * 4)
@@ -342,8 +353,9 @@ def test_full_size_frame_properties_on_the_benchmarked_mesh(R, tmp_path):
       seam that cuts through 16-row tiles), each equal the whole frame: per-pixel sums to 1e-12 relative (the order of the additions into a
       tile is the only freedom), ray and rejected-sample counts exactly;
     - a second render of the whole frame repeats the counts exactly;
-    - one sample per pixel of the whole frame against the oracle on the same streams (1.3 s of CPU): <= 1e-9 relative on >= 99.5 % of the
-      8.3 M pixels, ray counts within 0.2 %;
+    - one sample per pixel of the whole frame against the oracle on the same streams (1.3 s of CPU): <= 1e-9 relative on all but at most
+      1e-5 of the 8.3 M pixels (measured: 0, 0 and 2 pixels on the three 4K scenes), every one of those replayed on both sides and explained
+      by a libm call whose last bits differ between host and device (tests/divergence.py), ray counts within 0.02 %;
     - the fp32 mode traces the same paths up to fp32 silhouette grazes: ray count within 0.5 %, frame mean within 1 %."""
     from raytracing_amd.host_scenes import HostScene
     from raytracing_amd.tools.make_mesh import write_scene
@@ -377,6 +389,7 @@ def test_config3_soup_of_a_million_triangles_whole_frame(R, tmp_path):
     path = str(tmp_path / "soup1m.obj")
     n = write_soup(path, n_tri=1_000_000, n_mats=64, tex_size=256, extent=23.2, edge=0.2, seed=12345)
     assert n >= 1_000_000
+    from divergence import explain_pixel
     w, h, depth = 1920, 1080, 50
     hs = HostScene.obj(path, w, h, 1, cam_pos=(0, 2.3, 35.0), cam_lookat=(0, 0, 0), fov=40.0)
     osc = O.scene_from_arrays(hs.arrays(), 1)
@@ -386,6 +399,10 @@ def test_config3_soup_of_a_million_triangles_whole_frame(R, tmp_path):
     for mode in (R.MODE_FAST_FP64, R.MODE_REFERENCE_FP64):
         got, _, st = sc.render_to_host(w, h, 0, 1, depth, mode, seed=3)
         rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-        assert float((rel.max(axis=2) > 1e-9).mean()) <= 0.005, (mode, float((rel.max(axis=2) > 1e-9).mean()))
-        assert abs(st["rays"] - int(cnt[0])) <= 0.002 * int(cnt[0]), (mode, st["rays"], int(cnt[0]))
+        off = np.argwhere(rel.max(axis=2) > 1e-9)
+        assert len(off) <= 1e-5 * w * h, (mode, len(off))
+        for i, j in off:            # each one replayed and explained by a libm result of other last bits (tests/divergence.py)
+            e = explain_pixel(R, osc, sc, w, h, int(i), int(j), 1, 3, depth)
+            assert e["explained"], (mode, int(i), int(j), e)
+        assert abs(st["rays"] - int(cnt[0])) <= 0.0002 * int(cnt[0]), (mode, st["rays"], int(cnt[0]))
     sc.destroy(); osc.free(); hs.free()
