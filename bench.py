@@ -370,7 +370,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 rec = json.load(f).get(f"{args.workload}:{n_prims}:{args.mode}:{w}x{h}:d{args.depth}")
             if rec:
-                traffic = int(rec["bytes_per_ray"] * rays_per_launch)
+                per_launch = rays_per_launch if rec.get("ray_count") == "traced" else rays / max(args.steps, 1)     # older records are per trace() call
+                traffic = int(rec["bytes_per_ray"] * per_launch)
                 traffic_src = f"profiles/hbm_traffic.json: {rec['bytes_per_ray']:.1f} B/ray measured at {rec.get('spp_profiled')} spp ({rec.get('round', 'r01')}), x this launch's rays"
         except (OSError, ValueError):
             pass
@@ -405,10 +406,11 @@ def main():
                     "flop_per_ray": {"fp32": round(flop32, 1), "fp64": round(flop64, 1)}, "record_bytes_per_ray": round(bytes_per_ray, 1),
                     "node_record_bytes": node_bytes, "boxes_per_node_record": boxes_per_node, "leaf_record_bytes": leaf_bytes, "scene_MB": round(scene_mb, 1),
                     "note": "No dense contraction (no MFMA) and no HBM stream: node and primitive records are served by L1/L2/Infinity Cache (hbm_frac = measured "
-                            "memory-side bytes / time / 8 TB/s).  The nearest roof is VALU issue under wave64 divergence (PMC: vector ALU 62 % busy; waves spend 52 % of their cycles waiting on dependent round trips, profiles/r02_i_pmc_wave_stalls_*): frac = algorithmic flops "
-                            "(24 per fp32 box test, 40 per leaf test, 150 per ray of shading; leaf + shading in the result precision) / kernel time, "
-                            "against the vector peaks 157.3 (fp32) / 78.6 (fp64) TFLOP/s weighted by this mix (`peak`).  l1_frac = algorithmic record "
-                            "bytes / time against the vector-L1 peak"}
+                            "memory-side bytes / time / 8 TB/s).  The nearest roof is VALU issue under wave64 divergence: frac = algorithmic flops per ray that walked "
+                            "the tree (24 per fp32 box test, 40 per leaf test, 150 per ray of shading; leaf + shading in the result precision) x those rays / "
+                            "kernel time, against the vector peaks 157.3 (fp32) / 78.6 (fp64) TFLOP/s weighted by this mix (`peak`).  l1_frac = algorithmic record "
+                            "bytes / time against the vector-L1 peak.  `pmc` (stored passes of this command, same kernel variant): share of cycles the vector ALUs "
+                            "and the texture-address units are busy, resident waves per SIMD, issued VALU lane slots per ray, share of wave cycles spent waiting"}
         out = {
             "metric": "Mrays/s (node), path-traced frame, results in the reference's precision; image RMSE vs the reference CPU path in `image`",
             "value": round(total_rays / elapsed / 1e6, 2),            # rays that walked the tree / wall time

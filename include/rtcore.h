@@ -108,8 +108,10 @@ typedef struct rt_scene_desc {
 #define RT_MODE_FAST_FP64      3 /* the reference's arithmetic -- fp64, no FMA contraction, its evaluation order, for rays, primitive
                                     tests, hit records, shading and sums -- behind the library's SAH tree: boxes only cull (fp32,
                                     conservative), they never decide a hit, so closest hits, t bits and radiance are those of
-                                    RT_MODE_REFERENCE_FP64 except where two surfaces lie at the same t (the reference's visit order
-                                    picks one) and for volumes (their random draws follow the visit order).  accum_dev is double;
+                                    RT_MODE_REFERENCE_FP64.  Two surfaces at the same t (bit for bit): the reference keeps the one its
+                                    walk visits last, and so does this mode (ties are broken by the primitives' rank in the reference's
+                                    visit order; the one known residue: walls shared by two neighbouring `box` primitives).  Volumes draw
+                                    random numbers inside the traversal, so their streams follow the visit order.  accum_dev is double;
                                     sums are added per tile in completion order, so they match the reference mode's to rounding
                                     of the additions, not bit for bit.  Zero-direction rays (phong) against spheres
                                     follow the reference's NaN slabs only in RT_MODE_REFERENCE_FP64. */

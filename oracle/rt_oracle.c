@@ -1193,7 +1193,7 @@ static orc_obj* detached_sphere(orc_scene* s, v3 c, double radius, int mat)
  * cornell_box()).  As there: 400 ground boxes, rect light (not flipped: it shines upwards), moving / glass / fuzzy-metal
  * spheres, haze and blue-fog volumes, a sphere whose image texture fails to load (cyan, texture.hpp:97-99), a mirror sphere,
  * and translate(rotatey(bvh(1000 spheres))) -- all inside bvh(grp, 0, 1).  Same scene as ref_harness.cpp build_features. */
-orc_scene* orc_build_features(int width, int height, unsigned seed)
+static orc_scene* build_features(int width, int height, unsigned seed, int lit)
 {
     orc_scene* s = orc_scene_new(width, height, seed);
     orc_rng* g = &s->rng;
@@ -1229,12 +1229,19 @@ orc_scene* orc_build_features(int width, int height, unsigned seed)
     orc_obj* root = bvh_build(g, s->objects, 0, s->n_objects, 0, 1);   /* demo.hpp:141 */
     s->objects[0] = root;
     s->n_objects = 1;
-    orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 0, 1);
+    if (lit) {   /* the demo's own lamp faces up and the scene renders black: a flipped rect just under it, as an object and as the light */
+        orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 553, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 1, 0);
+        orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 553, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 1, 1);
+    }
+    else orc_add_plane(s, ORC_PLANEXZ, 123, 423, 147, 412, 554, orc_mat_emissive(s, orc_tex_constant(s, 7, 7, 7)), 0, 1);
     double pos[3] = { 478, 278, -600 }, at[3] = { 278, 278, 0 }, up[3] = { 0, 1, 0 };
     orc_set_camera(s, pos, at, up, 40, 0, 10, 0, 1);
     orc_build_bvh(s);
     return s;
 }
+orc_scene* orc_build_features(int width, int height, unsigned seed) { return build_features(width, height, seed, 0); }
+/* ... with a light that shines downwards (no counterpart in the reference; raytracing_amd/host rth_build_features_lit builds the same) */
+orc_scene* orc_build_features_lit(int width, int height, unsigned seed) { return build_features(width, height, seed, 1); }
 
 /* same scene as ref_harness.cpp build_smoke: sphere-bounded media (primitive.hpp:329-396) with fog (material.hpp:165-181) */
 orc_scene* orc_build_smoke(int width, int height, unsigned seed)

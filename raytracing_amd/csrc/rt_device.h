@@ -127,6 +127,9 @@ template <typename R> struct Scene {
     const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
     const WNode* wnodes; int32_t wide_stack;   // the same tree collapsed to quantised four-wide nodes; stack entries a traversal of it can need
     const Xform<R>* xforms;           // instance transforms (null: none)
+    const uint32_t* ref_rank;         // by primitive id: index of the LAST entry of `ops` that names it, i.e. when the reference's walk visits it last.
+                                      // Among surfaces at the same t (bit for bit) the reference ends up with the one it visits last (its range test
+                                      // lets t == t_max pass: polygon.hpp:113, primitive.hpp:42); the fast modes break such ties by this rank (take_hit)
     Camera<R> cam;
     __host__ __device__ Side<R> side() const { Side<R> s; s.tris = tris; s.xforms = xforms; return s; }
 };
@@ -445,6 +448,14 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
     case RT_PRIM_VOLUME: if constexpr (class_boxes(kFull)) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
+}
+
+// A leaf test of the fast modes passed with distance t: does the lane take it?  Nearer than the closest hit so far: yes.  At the SAME
+// distance (two coincident surfaces): the reference keeps whichever its own walk visits last, whatever order this tree visits them in.
+template <typename R> __device__ inline bool take_hit(const Scene<R>& sc, R t, R closest, int32_t cur_hit, int32_t new_id)
+{
+    if (t != closest || cur_hit < 0) return true;
+    return sc.ref_rank[new_id] > sc.ref_rank[sc.fprims[cur_hit].id];
 }
 
 // the primitive test behind every leaf; members of an instance are tested in the instance's frame (t is the same in both)

@@ -313,7 +313,7 @@ render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned l
                         if (kCount) vs.n_leaf++;
                         Prim<R> rec = *at32(fprims, (uint32_t) (first + k) * (uint32_t) sizeof(Prim<R>));
                         asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
-                        if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, nullptr)) { set_closest(tv, best, t); tv.hit = first + k; }
+                        if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, nullptr) && take_hit(sc, t, closest_of(tv, best), tv.hit, rec.id)) { set_closest(tv, best, t); tv.hit = first + k; }
                     }
                     tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
                 }

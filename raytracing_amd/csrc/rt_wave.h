@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     // dependent memory latencies per triangle (mesh workload -4.6 % time, leaf share of the wave time 21 -> 13 %)
                     Prim<R> rec = *at32(fprims, (uint32_t) (first + k) * (uint32_t) sizeof(Prim<R>));
                     asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
-                    if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, &g)) { set_closest(tv, best, t); tv.hit = first + k; }
+                    if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, &g) && take_hit(sc, t, closest_of(tv, best), tv.hit, rec.id)) { set_closest(tv, best, t); tv.hit = first + k; }
                 }
                 tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
                 RT_ASM_MARK("; leaf step end");
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256) first_hit_tree_kernel(Scene<R> sc, const 
             const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
             for (int k = 0; k < count; k++) {
                 R t;
-                if (prim_t<R, 2>(sc.fprims[first + k], sc.side(), r, consts<R>::tmin, closest_of(tv, best), t, nullptr)) { set_closest(tv, best, t); tv.hit = first + k; }
+                if (prim_t<R, 2>(sc.fprims[first + k], sc.side(), r, consts<R>::tmin, closest_of(tv, best), t, nullptr) && take_hit(sc, t, closest_of(tv, best), tv.hit, sc.fprims[first + k].id)) { set_closest(tv, best, t); tv.hit = first + k; }
             }
             tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
         }

@@ -319,8 +319,13 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
         }
         b = w;
     }
-    for (int k = 0; k < 3; k++) {   // pad flat boxes (rects, axis-aligned triangles) like the reference pads them (primitive.hpp:203, polygon.hpp:128)
-        double pad = 1e-4 + 1e-6 * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+    // Pad flat boxes (rects, axis-aligned triangles: zero extent along one axis).  The boxes only cull and are rounded outward to fp32
+    // afterwards, so the pad need not be the reference's (primitive.hpp:203 0.001, polygon.hpp:128 1e-7): it was 1e-4, a twentieth of an
+    // edge of the 1.3 M-triangle mesh on every side -- 5 % more leaf tests and 3.1 % more frame time than with 1e-6 (RT_BOX_PAD, 4K fp64:
+    // 43.82 ms at 1e-4, 42.49 at 1e-5, 42.45 at 1e-6, 42.91 at 0).
+    for (int k = 0; k < 3; k++) {
+        static const double pad_abs = std::getenv("RT_BOX_PAD") ? std::atof(std::getenv("RT_BOX_PAD")) : 1e-6;
+        double pad = pad_abs + 1e-6 * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
         b.lo[k] -= pad; b.hi[k] += pad;
     }
 }
@@ -375,7 +380,9 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     for (int i = 0; i < d->n_prims; i++) all_triangles &= d->prim_kind[i] == RT_PRIM_TRIANGLE;
     // SAH bins per axis: 64 for triangle meshes (-5 % frame time against 16 on the 0.3 / 1.3 / 5.2 M-triangle meshes alike; 128 and more
     // gained nothing), 16 for scenes with spheres (64: +4 %)
-    int leaf_max = 4, depth_limit = 26, bins = all_triangles ? 64 : 16; double c_prim = all_triangles ? 1.0 : 1.5;
+    // leaves of at most two triangles: the same box and leaf tests per ray as with four (18.2 / 2.07 on the 1.3 M-triangle mesh), but the leaf
+    // step's record loop ends for all lanes after two rounds: 4K fp64 42.56 ms at 4, 42.42 at 3, 41.84 at 2
+    int leaf_max = all_triangles ? 2 : 4, depth_limit = 26, bins = all_triangles ? 64 : 16; double c_prim = all_triangles ? 1.0 : 1.5;
     if (const char* e = std::getenv("RT_BVH_BINS")) bins = std::atoi(e);
     if (const char* e = std::getenv("RT_BVH_LEAF")) leaf_max = std::atoi(e);
     if (const char* e = std::getenv("RT_BVH_CPRIM")) c_prim = std::atof(e);
@@ -498,6 +505,11 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     if ((rc = upload(out.owned, lights, &v.lights))) return rc;
     if (d->n_xforms) { if ((rc = upload(out.owned, xforms, &v.xforms))) return rc; } else v.xforms = nullptr;
     if (light_tri) { if ((rc = upload(out.owned, ltris, &v.light_tris))) return rc; } else v.light_tris = nullptr;
+    {   // when the reference's walk visits each primitive last (rt_device.h Scene::ref_rank)
+        std::vector<uint32_t> rank(d->n_prims, 0u);
+        for (int i = 0; i < n_ops; i++) if (f.op_prim[i] >= 0) rank[f.op_prim[i]] = (uint32_t) i;
+        if ((rc = upload(out.owned, rank, &v.ref_rank))) return rc;
+    }
     v.n_ops = n_ops; v.n_prims = d->n_prims; v.n_lights = d->n_lights; v.need_uv = need_uv;
     const double* c = d->camera;
     auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };

@@ -36,7 +36,8 @@ def lib():
         L.orc_build_cornell.restype = C.c_void_p
         L.orc_build_smoke.restype = C.c_void_p
         L.orc_build_features.restype = C.c_void_p
-        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke", "orc_build_features"):
+        L.orc_build_features_lit.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke", "orc_build_features", "orc_build_features_lit"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         _lib = L
     return _lib
@@ -75,6 +76,11 @@ class Scene:
     def features(cls, width, height, seed=1):
         """all_feature_test() (demo.hpp:94-143) under a light and a camera: ref_harness.cpp build_features"""
         return cls(lib().orc_build_features(width, height, seed), width, height)
+
+    @classmethod
+    def features_lit(cls, width, height, seed=1):
+        """all_feature_test() under a flipped rect light just below the demo's own (which faces up)"""
+        return cls(lib().orc_build_features_lit(width, height, seed), width, height)
 
     @classmethod
     def cornell(cls, width, height, seed=1):

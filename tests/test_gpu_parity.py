@@ -169,8 +169,12 @@ def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, 
     (rt_first_hit, itself bit-exact against the fixtures of the real reference): primitive id, t BITS and frontward flag must be
     equal on every fixture ray.  Nothing is thresholded; the rays that may differ are of three kinds, each recognised exactly and
     counted:
-      ties     two surfaces at the same t bits (the Cornell box's bottom face in the floor plane, neighbouring ground boxes of
-               all_feature_test sharing a wall): the reference's answer is its visit order's, t and frontward must still agree;
+      ties     two surfaces at the same t bits.  The reference ends up with the one its walk visits LAST (its range tests let t == t_max
+               pass), and so do the fast modes since round 3: equal distances are broken by the primitives' rank in the reference's
+               visit order (rt_device.h take_hit) -- the Cornell box's bottom face in the floor plane (27 rays before), the n-gon
+               fixture's coincident faces of opposite orientation (19) now come out as the reference's.  What is left: 10 rays of
+               all_feature_test between neighbouring ground BOXES sharing a wall (a box is six rects behind one record; which of two
+               boxes' walls the reference keeps depends on its t_max at that moment); t and frontward still agree there;
       zero     the fixture's all-zero-direction rays (what phong leaves in `wo`): every slab is NaN in the reference's
                aabb test and sphere roots are 0/0 -- only the reference-order walk imitates that;
       msphere  a moving sphere directly under scene::build_bvh is bounded at time 0 only (scene.hpp:49 passes the range (0,0)),
@@ -186,13 +190,18 @@ def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, 
     a, b = sc.first_hit(rays), sc.first_hit_tree(rays, fp64=True)
     diff = (a["prim"] != b["prim"]) | (a["t"].view(np.uint64) != b["t"].view(np.uint64)) | (a["front"] != b["front"])
     zero = np.all(rays[:, 3:6] == 0, axis=1)
-    tie = diff & ~zero & (a["prim"] >= 0) & (b["prim"] >= 0) & (a["t"].view(np.uint64) == b["t"].view(np.uint64)) & (a["front"] == b["front"])
+    tie = diff & ~zero & (a["prim"] >= 0) & (b["prim"] >= 0) & (a["t"].view(np.uint64) == b["t"].view(np.uint64))
+    # a tie on an edge shared by two faces of different orientation (the n-gon fixture's prisms) may also differ in `frontward`: each
+    # side reports its own primitive's flag; elsewhere (coplanar ties) the flags must agree
+    edge = tie & (a["front"] != b["front"])
+    assert int(edge.sum()) == 0, int(edge.sum())
     kind = np.asarray(d["prim_kind"])
     with np.errstate(invalid="ignore"):
         msphere = diff & ~zero & (b["prim"] >= 0) & (kind[np.maximum(b["prim"], 0)] == 2) & ((a["prim"] < 0) | (b["t"] < a["t"]))
     unexplained = diff & ~zero & ~tie & ~msphere
     assert not unexplained.any(), [(int(i), rays[i].tolist(), int(a["prim"][i]), float(a["t"][i]), int(b["prim"][i]), float(b["t"][i])) for i in np.nonzero(unexplained)[0][:5]]
-    limits = {"cornell": (40, 0), "features": (60, 0), "mixed": (0, 4), "smoke": (0, 6)}.get(name, (0, 0))
+    limits = {"features": (12, 0), "mixed": (0, 4), "smoke": (0, 6)}.get(name, (0, 0))      # measured: features 10 ties, mixed 2 / smoke 3 moving-sphere rays
+    print(f"[first hits through the fast tree] {name} qnodes={qnodes}: {int(diff.sum())} of {len(rays)} rays differ: ties {int(tie.sum())} (edge {int(edge.sum())}), zero-direction {int((diff & zero).sum())}, msphere {int(msphere.sum())}")
     assert int(tie.sum()) <= limits[0] and int(msphere.sum()) <= limits[1], (int(tie.sum()), int(msphere.sum()))
     assert int((~diff).sum()) >= len(rays) - 64
     sc.destroy()
@@ -723,6 +732,32 @@ def test_all_feature_test_lit_radiance_fast_modes_vs_reference_mode(R):
         assert got <= 1.25 * floor, (mode, got, floor)
         assert abs(c.mean() - a.mean()) <= 0.02 * a.mean(), (mode, c.mean(), a.mean())
     sc.destroy(); hs.free()
+
+
+def test_all_feature_test_lit_reference_mode_matches_the_oracle_on_the_same_streams(R):
+    """The lit all_feature_test() against the CPU ORACLE (the test above compares GPU modes with each other): the fp64 reference mode walks
+    the reference tree in the reference's order, so its media draw their free-flight distances at the same stream positions as the
+    oracle's, and the frame must agree pixel by pixel -- boxes, media (log), the instanced cloud through both wrappers' set_face_normal,
+    glass, fuzzy metal, the cyan texture: <= 1e-9 relative but for pixels explained by a libm call of other last bits, ray and
+    rejected-sample counts to 0.1 %.  The host mirror's rth_build_features_lit builds the same scene: its flattened arrays equal the
+    oracle's export."""
+    from divergence import assert_same_streams
+    from raytracing_amd.host_scenes import HostScene
+    w, h, spp, depth = 48, 32, 16, 10
+    osc = O.Scene.features_lit(w, h, 4)
+    want, _, cnt = osc.render(0, spp, depth, O.RNG_COUNTER, seed=21, n_threads=8)
+    assert want.mean() > 0.01, "lit"
+    d = osc.export()
+    hs = HostScene.features_lit(w, h, 4)
+    mine = hs.arrays()
+    for key in ("prim_kind", "prim_data", "node_child", "node_bbox", "light_data", "xform_data", "camera"):
+        a = np.asarray(mine[key]); b = np.asarray(d[key], dtype=a.dtype)
+        assert a.size == b.size and np.array_equal(a.ravel().view(np.uint8), b.ravel().view(np.uint8)), key
+    sc = R.Scene(d)
+    got, _, st = sc.render_to_host(w, h, 0, spp, depth, R.MODE_REFERENCE_FP64, seed=21)
+    assert_same_streams(R, osc, sc, got, want, w, h, spp, 21, depth, max_frac=0.01)
+    assert abs(st["rays"] - int(cnt[0])) <= 1e-3 * int(cnt[0]) and abs(st["rejected"] - int(cnt[1])) <= 1e-3 * int(cnt[1]) + 2, (st, cnt)
+    sc.destroy(); hs.free(); osc.free()
 
 
 @pytest.mark.parametrize("name", ["c0_seed1", "mixed", "obj", "cornell"])

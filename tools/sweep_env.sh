@@ -1,0 +1,9 @@
+# one fp64 mesh timing (4K, 32 spp, counting pass) per value of an environment variable.  usage: bash tools/sweep_env.sh NAME v1 v2 ...
+set -e
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+NAME=$1; shift
+for v in "$@"; do
+  echo "== $NAME=$v"
+  env $NAME=$v timeout -k 10 120 python3 tools/sweep_wave.py obj --mode fp64 --spp 32 --width 3840 --height 2160 --count 2>&1 | grep "^obj" | sed 's/| lane-eff.*| per ray/| per ray/'
+done
