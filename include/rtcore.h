@@ -43,15 +43,23 @@ extern "C" {
 #define RT_PRIM_BOX      7  /* box      primitive.hpp:399-458, optionally inside rotatey and then translate (transform.hpp:9-121), as
                                cornell_box() builds it (demo.hpp:80-88): one leaf of the bvh.
                                data: minimum[3], maximum[3], sin_theta, cos_theta, target[3]                  */
-#define RT_PRIM_VOLUME   8  /* volume   primitive.hpp:329-396 around a sphere boundary: a constant-density medium; its material must be
-                               RT_MAT_FOG.  data: c[3], radius, neg_inv_d (= -1 / density).  The free-flight distance is drawn inside the
-                               intersection test (:373): such a primitive is never hit by rt_first_hit / rt_first_hit_fast, which have
-                               no random stream, and RT_FLAG_WAVEFRONT rejects scenes that contain one                                 */
+#define RT_PRIM_VOLUME   8  /* volume   primitive.hpp:329-396: a constant-density medium inside a boundary object; its material must be
+                               RT_MAT_FOG.  Boundary a sphere: data c[3], radius, neg_inv_d (= -1 / density).  Boundary a box
+                               (RT_PRIM_FLAG_BOUNDARY_BOX), optionally inside rotatey and then translate as RT_PRIM_BOX takes them
+                               (volume(translate(rotatey(box)))): data minimum[3], maximum[3], sin_theta, cos_theta, target[3], neg_inv_d.
+                               The free-flight distance is drawn inside the intersection test (:373): such a primitive is never hit by
+                               rt_first_hit / rt_first_hit_fast, which have no random stream, and RT_FLAG_WAVEFRONT rejects scenes that
+                               contain one                                                                                              */
 #define RT_PRIM_STRIDE  24  /* doubles per primitive record */
 #define RT_XFORM_STRIDE  6  /* doubles per instance transform */
-#define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` */
-#define RT_PRIM_FLAG_ROTATEY 2   /* RT_PRIM_BOX: wrapped in rotatey (sin_theta, cos_theta as its constructor computes them) */
-#define RT_PRIM_FLAG_TRANSLATE 4 /* RT_PRIM_BOX: wrapped (outermost) in translate(target) */
+#define RT_PRIM_FLAG_FLIP 1 /* wrapped in flip (transform.hpp:124-149): toggles `frontward` of the leaf's own record, i.e. BEFORE the record passes
+                               through the wrappers of prim_xform (whose set_face_normal calls then overwrite it, as in the reference) */
+#define RT_PRIM_FLAG_ROTATEY 2   /* RT_PRIM_BOX (or a volume's boundary box): wrapped in rotatey (sin_theta, cos_theta as its constructor computes them) */
+#define RT_PRIM_FLAG_TRANSLATE 4 /* RT_PRIM_BOX (or a volume's boundary box): wrapped (outermost) in translate(target) */
+#define RT_PRIM_FLAG_BOUNDARY_BOX 8  /* RT_PRIM_VOLUME: the boundary is a box (see above), not a sphere */
+#define RT_PRIM_FLAG_FLIP_OUTER 16   /* a flip OUTSIDE every wrapper of prim_xform (flip(translate(x)), flip(bvh) around an instance): toggles
+                                        `frontward` after the record has come back out of the whole chain */
+#define RT_XFORM_FLAG_CHAIN 8    /* instance transform record: the NEXT record (index + 1) continues this transform towards the object */
 
 /* material kinds (material.hpp) and the layout of their RT_MAT_STRIDE doubles */
 #define RT_MAT_LAMBERTIAN 1 /* tex = base_color                                  */
@@ -73,6 +81,10 @@ typedef struct rt_scene rt_scene;   /* opaque: a scene resident in HBM */
 /* A built scene, flattened.  Caller keeps ownership; rt_scene_create copies everything it needs.
  * The BVH is the reference's own tree (bvh.hpp:22-56), node by node: child code c >= 0 is node c, c < 0 is
  * primitive ~c.  `roots` lists scene.objects' children in order (one entry after scene::build_bvh, scene.hpp:46-51).
+ * A `group` used as an object inside the tree (a leaf of a bvh, a member of another group; group.hpp:68-83) is a chain of GROUP LINKS:
+ * a node whose box is inverted (min[0] > max[0]; the flattener writes +inf / -inf) has no box test -- its two children are
+ * intersected in order with the running t_max, which is what group::intersect's loop does; members m0..mk become
+ * link(m0, link(m1, ... link(mk-1, mk))), a group of one is its member.
  * Primitive ids are insertion order into the scene, before the builder permutes the array. */
 typedef struct rt_scene_desc {
     int32_t n_nodes;  const double* node_bbox;   /* n_nodes x 6: min xyz, max xyz */
@@ -89,13 +101,16 @@ typedef struct rt_scene_desc {
     /* camera after setup_camera (camera.hpp:46-60): position[3], left_bottom[3], horizontal[3], vertical[3],
      * u[3], v[3], w[3], lens_radius, shutter_start, shutter_end */
     double camera[24];
-    /* instances: a bvh (or a single primitive) wrapped in rotatey and / or translate (transform.hpp:9-121), as all_feature_test()
+    /* instances: a bvh, a group or a single primitive wrapped in rotatey and / or translate (transform.hpp:9-121), as all_feature_test()
      * builds (demo.hpp:136-140).  Members keep their object-space geometry -- node boxes and primitive records -- and name their
-     * transform; rays are taken into that frame for every test and hit records come back out through both wrappers'
-     * set_face_normal calls.  RT_PRIM_BOX keeps carrying its own wrappers in its record (prim_xform -1).  n_xforms == 0: the two
-     * index arrays may be NULL. */
-    int32_t n_xforms; const double* xform_data;  /* n_xforms x RT_XFORM_STRIDE: sin_theta, cos_theta, target[3], wrappers
-                                                     (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE; translate is the outer one) */
+     * transform; rays are taken into that frame for every test and hit records come back out through every wrapper's
+     * set_face_normal call, innermost first.  One record holds translate(rotatey(.)), rotatey(.) or translate(.); any other nesting --
+     * translate(translate(.)), rotatey(translate(.)), an instance inside an instance -- is a CHAIN of consecutive records, outermost
+     * first, each but the last flagged RT_XFORM_FLAG_CHAIN; node_xform / prim_xform name a chain's first record.  RT_PRIM_BOX may keep
+     * its innermost translate(rotatey(.)) in its own record (prim_xform -1 when that is all).  n_xforms == 0: the two index arrays may
+     * be NULL. */
+    int32_t n_xforms; const double* xform_data;  /* n_xforms x RT_XFORM_STRIDE: sin_theta, cos_theta, target[3], flags
+                                                     (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE | RT_XFORM_FLAG_CHAIN; translate is the outer one) */
                       const int32_t* node_xform; /* n_nodes: transform index, -1 = world space */
                       const int32_t* prim_xform; /* n_prims: transform index, -1 = world space */
 } rt_scene_desc;

@@ -528,6 +528,8 @@ def main():
         "smoke": (["smoke", 2, 64, 48, 16, 12], dict(seed=2, width=64, height=48, spp=16, depth=12)),
         # all_feature_test() (demo.hpp:94-143): 400 boxes, media, a failed image texture, translate(rotatey(bvh(1000 spheres)))
         "features": (["features", 4, 48, 32, 4, 10], dict(seed=4, width=48, height=32, spp=4, depth=10)),
+        # what the object model composes and the demos do not: nested wrappers, volumes around boxes, groups as objects, instance in instance
+        "nested": (["nested", 3, 60, 40, 8, 12], dict(seed=3, width=60, height=40, spp=8, depth=12)),
     }
     only = sys.argv[1:]          # optional: names of the fixtures to (re)generate
     if not only or "images" in only:

@@ -72,6 +72,11 @@ static double sm_range(double a, double b) { return a + (b - a) * sm_unit(); }
 // ---------------------------------------------------------------- tree dump
 enum { K_NODE = 0, K_SPHERE = 1, K_MSPHERE = 2, K_PLANEXY = 3, K_PLANEXZ = 4, K_PLANEYZ = 5, K_TRIANGLE = 6, K_BOX = 7, K_VOLUME = 8 };
 enum { ROW = 56 };   // doubles per pre-order entry
+enum { K_GROUP = 9 };  // a group used as an object (group.hpp:12): one entry, like an instance
+// the `nested` fixture also dumps every entry's wrapper chain (row[28]: base-4 digits outermost first, 1 flip 2 rotatey 3 translate;
+// row[29]: a position-weighted sum of the wrappers' parameters) and a volume's boundary (g[5], g[6..11]); the older fixtures' rows
+// stay as they were made
+static bool g_wrapper_rows = false;
 
 struct pentry {
     const object* o; const object* base; int flipped; int left; int right;
@@ -152,6 +157,17 @@ struct tree_dump {
             double* g = r + 4;                 // geometry block, 24 doubles
             double* m = r + 30;                // material block
             const material* mat = nullptr;
+            if (g_wrapper_rows) {
+                double code = 0, sum = 0; int k = 1;
+                for (const object* w = e.o; ; k++) {
+                    if (const flip* f = dynamic_cast<const flip*>(w)) { code = code * 4 + 1; w = f->obj; }
+                    else if (const rotatey* ro = dynamic_cast<const rotatey*>(w)) { code = code * 4 + 2; sum += k * (ro->sin_theta + 2 * ro->cos_theta); w = ro->obj; }
+                    else if (const translate* tr = dynamic_cast<const translate*>(w)) { code = code * 4 + 3; sum += k * (tr->target.x() + 2 * tr->target.y() + 3 * tr->target.z()); w = tr->obj; }
+                    else break;
+                }
+                r[28] = code; r[29] = sum;
+            }
+            if (const group* gr = dynamic_cast<const group*>(e.base)) { r[0] = K_GROUP; g[0] = gr->size(); continue; }
             if (const bvh* b = dynamic_cast<const bvh*>(e.base)) {
                 r[0] = K_NODE;
                 for (int k = 0; k < 3; k++) { g[k] = b->bbox.min()[k]; g[3 + k] = b->bbox.max()[k]; }
@@ -190,6 +206,19 @@ struct tree_dump {
                 r[0] = K_VOLUME;
                 if (sb) { for (int k = 0; k < 3; k++) g[k] = sb->center[k]; g[3] = sb->radius; }
                 g[4] = vo->neg_inv_d; mat = vo->mat;
+                if (g_wrapper_rows) {                                   // the boundary: wrappers (same digits), then sphere (1) / box (7) and a box's corners
+                    double code = 0;
+                    const object* w = vo->surface;
+                    for (;;) {
+                        if (const flip* f = dynamic_cast<const flip*>(w)) { code = code * 4 + 1; w = f->obj; }
+                        else if (const rotatey* ro = dynamic_cast<const rotatey*>(w)) { code = code * 4 + 2; w = ro->obj; }
+                        else if (const translate* tr = dynamic_cast<const translate*>(w)) { code = code * 4 + 3; w = tr->obj; }
+                        else break;
+                    }
+                    const box* bb = dynamic_cast<const box*>(w);
+                    g[5] = code * 16 + (dynamic_cast<const sphere*>(w) ? 1 : bb ? 7 : 0);
+                    if (bb) for (int k = 0; k < 3; k++) { g[6 + k] = bb->minimum[k]; g[9 + k] = bb->maximum[k]; }
+                }
             } else {
                 r[0] = -1;
             }
@@ -343,6 +372,86 @@ static built_scene* build_features(int w, int h)
     return b;
 }
 
+// Everything the reference's object model composes and the demos never do: wrappers nested every way (transform.hpp:9-149), volumes
+// around boxes (primitive.hpp:332-343 takes any object*), groups used as objects (group.hpp:12,68-102), an instance inside an
+// instance.  Every leaf gets a material of its own, registered in construction order: the hit record's `mat` then names the LEAF
+// that was hit, also inside a wrapper, a group or an instance (fixture array <tag>_fh_prim).
+static std::map<const material*, int> g_leaf_of_mat;
+static material* leaf_mat(material* m) { int n = (int) g_leaf_of_mat.size(); g_leaf_of_mat[m] = n; return m; }
+static material* leaf_lam(double r, double g, double b) { return leaf_mat(new lambertian(vec3d(r, g, b))); }
+static object* leaf_volume(object* surface, double density, const vec3d& color) { volume* v = new volume(surface, density, color); leaf_mat(v->mat); return v; }
+
+static built_scene* build_nested(int w, int h)
+{
+    built_scene* b = new built_scene();
+    b->scn = new scene(w, h);
+    group grp;
+    // 0 ground, 1 lamp
+    grp.add(new planexz(-40, 40, -40, 40, 0, leaf_lam(0.5, 0.5, 0.5)));
+    grp.add(new flip(new planexz(-4, 4, -4, 4, 14, leaf_mat(new emissive(vec3d(8, 8, 8))))));
+    // 2 translate(translate(sphere))
+    grp.add(new translate(new translate(new sphere(vec3d(0, 1, 0), 1, leaf_lam(0.8, 0.3, 0.3)), vec3d(-6, 0, 0)), vec3d(0, 0, -3)));
+    // 3 translate(rotatey(rotatey(box)))
+    grp.add(new translate(new rotatey(new rotatey(new box(vec3d(-1, 0, -1), vec3d(1, 2, 1), leaf_lam(0.3, 0.8, 0.3)), 20), 25), vec3d(-2, 0, 4)));
+    // 4 translate(rotatey(translate(rotatey(sphere)))), glass
+    grp.add(new translate(new rotatey(new translate(new rotatey(new sphere(vec3d(0, 1, 0), 1, leaf_mat(new dielectric(1.5))), 30), vec3d(3, 0, 0)), 40), vec3d(2, 0, -6)));
+    // 5 rotatey(translate(sphere)), metal
+    grp.add(new rotatey(new translate(new sphere(vec3d(0, 1.2, 0), 1.2, leaf_mat(new metal(vec3d(0.8, 0.8, 0.6), 0.1))), vec3d(7, 0, 0)), 50));
+    // 6 volume(box)
+    grp.add(leaf_volume(new box(vec3d(-9, 0, 2), vec3d(-6, 3, 5), new dielectric(1.5)), 0.4, vec3d(0.9, 0.9, 0.9)));
+    // 7 volume(translate(rotatey(box)))
+    grp.add(leaf_volume(new translate(new rotatey(new box(vec3d(0, 0, 0), vec3d(2.5, 3, 2.5), new dielectric(1.5)), -18), vec3d(5, 0, 3)), 0.5, vec3d(0.2, 0.4, 0.9)));
+    // 8 translate(volume(sphere))
+    grp.add(new translate(leaf_volume(new sphere(vec3d(0, 1.5, 0), 1.5, new dielectric(1.5)), 0.6, vec3d(0.9, 0.5, 0.2)), vec3d(-3, 0, -8)));
+    // 9-11 a group as an object
+    {
+        group* sub = new group();
+        sub->add(new sphere(vec3d(-10, 1, -6), 1, leaf_lam(0.7, 0.7, 0.2)));
+        sub->add(new triangle(vec3d(-12, 0, -4), vec3d(-9, 0, -4), vec3d(-10.5, 3, -4.5), leaf_lam(0.2, 0.7, 0.7)));
+        sub->add(new box(vec3d(-13, 0, -9), vec3d(-11, 2, -7), leaf_lam(0.7, 0.2, 0.7)));
+        grp.add(sub);
+    }
+    // 12-13 translate(group)
+    {
+        group* sub = new group();
+        sub->add(new sphere(vec3d(0, 1, 0), 1, leaf_lam(0.9, 0.6, 0.3)));
+        sub->add(new sphere(vec3d(2.2, 1, 0), 1, leaf_mat(new metal(vec3d(0.9, 0.9, 0.9), 0.0))));
+        grp.add(new translate(sub, vec3d(8, 0, -9)));
+    }
+    // 14-18 an instance inside an instance: translate(rotatey(bvh{ sphere, translate(bvh{3 spheres}), sphere }))
+    {
+        group in;
+        in.add(new sphere(vec3d(0, 0.6, 0), 0.6, leaf_lam(0.9, 0.2, 0.2)));
+        in.add(new sphere(vec3d(1.5, 0.6, 0), 0.6, leaf_lam(0.2, 0.9, 0.2)));
+        in.add(new sphere(vec3d(0, 0.6, 1.5), 0.6, leaf_lam(0.2, 0.2, 0.9)));
+        object* inner = new bvh(in);
+        group mid;
+        mid.add(new sphere(vec3d(-2, 1, 0), 1, leaf_lam(0.6, 0.6, 0.6)));
+        mid.add(new translate(inner, vec3d(0, 2.2, 0)));
+        mid.add(new sphere(vec3d(2.5, 1, 1), 1, leaf_mat(new dielectric(1.5))));
+        grp.add(new translate(new rotatey(new bvh(mid), 35), vec3d(-9, 0, 9)));
+    }
+    // 19 flip(translate(sphere)): the flip counts.  20 translate(flip(sphere)): translate's set_face_normal overwrites it
+    grp.add(new flip(new translate(new sphere(vec3d(0, 1, 0), 1, leaf_mat(new dielectric(1.5))), vec3d(4, 0, 8))));
+    grp.add(new translate(new flip(new sphere(vec3d(0, 1, 0), 1, leaf_mat(new dielectric(1.5)))), vec3d(7, 0, 7)));
+    // 21-22 flip(bvh{sphere, rect})
+    {
+        group m;
+        m.add(new sphere(vec3d(11, 1, 2), 1, leaf_mat(new dielectric(1.5))));
+        m.add(new planexy(9, 13, 0, 3, 0, leaf_lam(0.4, 0.4, 0.8)));
+        grp.add(new flip(new bvh(m)));
+    }
+    // 23 translate(msphere)
+    grp.add(new translate(new msphere(vec3d(0, 1, 0), vec3d(0, 1.5, 0), 0, 1, 0.8, leaf_lam(0.7, 0.3, 0.1)), vec3d(-5, 0, 6)));
+    b->scn->add_object(grp);
+    b->scn->add_light(new flip(new planexz(-4, 4, -4, 4, 14, new emissive(vec3d(8, 8, 8)))));
+    b->scn->set_camera(camera(vec3d(2, 9, 26), vec3d(0, 1, 0), vec3d(0, 1, 0), 40, double(w) / h, 0.1, 25, 0, 1));
+    b->scn->build_bvh();
+    b->root = b->scn->objects.content()[0];
+    b->td.walk(b->root);
+    return b;
+}
+
 // OBJ scene through the reference loader (loader.hpp:20-38)
 static built_scene* build_obj(const char* path, int w, int h)
 {
@@ -415,7 +524,7 @@ static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_si
 
     size_t n = rays.size();
     std::vector<double> rin(n * 7), tout(n), rec(n * 9);
-    std::vector<int32_t> hit(n), nbox(n), nleaf(n), front(n);
+    std::vector<int32_t> hit(n), nbox(n), nleaf(n), front(n), leaf(n);
     std::vector<uint64_t> hash(n);
     size_t mism = 0;
     for (size_t i = 0; i < n; i++) {
@@ -436,6 +545,7 @@ static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_si
         tout[i] = h ? x.t : 0.0;
         nbox[i] = st.nbox; nleaf[i] = st.nleaf; hash[i] = st.hash;
         front[i] = h ? (int) x.frontward : -1;
+        leaf[i] = h && g_leaf_of_mat.count(x.mat) ? g_leaf_of_mat.at(x.mat) : -1;
         if (h) {
             for (int k = 0; k < 3; k++) { rec[i * 9 + k] = x.position[k]; rec[i * 9 + 3 + k] = x.normal[k]; }
             rec[i * 9 + 6] = x.uv_coord.content[0]; rec[i * 9 + 7] = x.uv_coord.content[1]; rec[i * 9 + 8] = 0;
@@ -451,6 +561,7 @@ static void do_firsthit(const std::string& tag, built_scene* b, int n_primary_si
     dump_i32((tag + "_fh_front").c_str(), front);
     dump_u64((tag + "_fh_hash").c_str(), hash);
     dump_f64((tag + "_fh_rec").c_str(), rec);
+    if (!g_leaf_of_mat.empty()) dump_i32((tag + "_fh_prim").c_str(), leaf);     // the leaf behind the hit record's material (build_nested)
 }
 
 // ---------------------------------------------------------------- image fixture
@@ -699,6 +810,18 @@ int main(int argc, char** argv)
         double lo[3] = { -200, 1, -200 }, hi[3] = { 554, 554, 600 };
         do_firsthit("features", b, 32, 1024, lo, hi, false);
         do_image("features", b, w, h, spp, depth);
+    }
+    else if (mode == "nested") {        // nested <seed> <w> <h> <spp> <depth>
+        unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+        srand(seed);
+        g_wrapper_rows = true;
+        built_scene* b = build_nested(w, h);
+        dump_f64("nested_tree", b->td.rows());
+        dump_lights("nested_lights", *b->scn);
+        dump_camera("nested_camera", b->scn->render_camera);
+        double lo[3] = { -14, 0.1, -12 }, hi[3] = { 14, 8, 12 };
+        do_firsthit("nested", b, 32, 1536, lo, hi, false);      // volumes draw from rand() during the walks
+        do_image("nested", b, w, h, spp, depth);
     }
     else if (mode == "time_c0") {       // time_c0 <seed> <w> <h> <spp> <depth> : throughput of the real reference, 1 thread
         unsigned seed = atoi(argv[3]); int w = atoi(argv[4]), h = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);

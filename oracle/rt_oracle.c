@@ -217,13 +217,14 @@ typedef struct { int kind; double d[ORC_TEX_STRIDE]; const uint8_t* pixels; int 
 typedef struct { int kind; int tex; double d[ORC_MAT_STRIDE]; } orc_mat;
 /* mat d[]: [0] roughness | ior ; phong: [1..3] Kd [4..6] Ks [7..9] Ke [10..12] Tr [13] Ns [14] Ni */
 
-enum { O_BVH = 100, O_FLIP = 101, O_TRANSLATE = 102, O_ROTATEY = 103 };   /* translate: g[0..2] target; rotatey: g[0] sin, g[1] cos, g[2] has_bbox, box */
+enum { O_BVH = 100, O_FLIP = 101, O_TRANSLATE = 102, O_ROTATEY = 103, O_GROUP = 104 };   /* translate: g[0..2] target; rotatey: g[0] sin, g[1] cos, g[2] has_bbox, box; group: items */
 typedef struct orc_obj {
     int kind;                 /* ORC_SPHERE.. | O_BVH | O_FLIP */
     int id;                   /* prim id (insertion order into scene.objects), -1 for bvh nodes / light-only objects */
     int mat;
     double g[ORC_PRIM_STRIDE];
     struct orc_obj *l, *r;    /* bvh children; flip / translate / rotatey / volume: l = inner */
+    struct orc_obj** items; int n_items;   /* group used as an object (group.hpp:12-124) */
     int first_entry;          /* first pre-order index (pre-order view), -1 until walked */
     aabb box;                 /* bvh */
 } orc_obj;
@@ -244,6 +245,7 @@ struct orc_scene {
     const orc_obj** pre; int* pre_first; int* pre_left; int* pre_right; int n_pre;
     int* root_entry;
     uint64_t rays;
+    int wrapper_rows; /* orc_tree_rows also writes the wrapper chain of every entry (the `nested` fixture; ref_harness.cpp g_wrapper_rows) */
     int early_exit;   /* stop a path once its sample is known to be rejected (same image, fewer rays) */
     int compat_fixed; /* no counterpart in the reference: the estimator with its defects repaired (see orc_set_compat_fixed) */
 };
@@ -539,6 +541,7 @@ static int box_hit(const orc_obj* o, const ray* r, isect* x)
 }
 
 static int obj_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g);
+static int group_hit(orc_obj* const* objs, int n, const ray* r, isect* x, orc_rng* g);
 
 static int bvh_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g) /* bvh.hpp:58-68 */
 {
@@ -590,9 +593,10 @@ static int obj_hit(const orc_obj* o, const ray* r, isect* x, orc_rng* g)
     case O_FLIP:                                                        /* transform.hpp:129-136 */
         if (!obj_hit(o->l, r, x, g)) return 0;
         x->front = !x->front;
-        x->leaf = o;
+        if (o->id >= 0) x->leaf = o;                                    /* (a flip registered as the primitive; else the leaf found inside) */
         return 1;
     case O_BVH: return bvh_hit(o, r, x, g);
+    case O_GROUP: return group_hit(o->items, o->n_items, r, x, g);      /* a group used as an object: group.hpp:68-83 */
     case O_TRANSLATE: {                                                 /* transform.hpp:18-28 */
         const v3 target = V(o->g[0], o->g[1], o->g[2]);
         ray off = mkray(vsub(r->o, target), r->d, r->time, r->t_min, r->t_max);
@@ -692,6 +696,18 @@ static int obj_bbox(const orc_obj* o, double start, double end, aabb* out)
         return 1;
     }
     case O_ROTATEY: *out = o->box; return (int) o->g[2];                /* transform.hpp:112-116 */
+    case O_GROUP: {                                                     /* group.hpp:85-102: `first` is never true, so the result is the union of
+                                                                           whatever the CALLER's box held (a fresh aabb: zeros) with every member's;
+                                                                           temp_bbox lives across the loop, so a member that is itself a group
+                                                                           starts from its predecessor's box */
+        if (o->n_items == 0) return 0;
+        aabb tmp; memset(&tmp, 0, sizeof tmp);
+        for (int i = 0; i < o->n_items; i++) {
+            if (!obj_bbox(o->items[i], start, end, &tmp)) return 0;
+            *out = surrounding(*out, tmp);
+        }
+        return 1;
+    }
     }
     return 0;
 }
@@ -760,7 +776,8 @@ static v3 lights_rand(const orc_scene* s, orc_rng* g, v3 origin)        /* group
 /* ------------------------------------------------------------------ bvh build (bvh.hpp:22-56) */
 static double bbox_key(const orc_obj* o, int axis)                      /* bvh.hpp:76-83: boxes at time (0,0) */
 {
-    aabb b; obj_bbox(o, 0, 0, &b);
+    aabb b; memset(&b, 0, sizeof b);                                   /* a fresh aabb (zeros): a group's box starts from it */
+    obj_bbox(o, 0, 0, &b);
     return vget(b.mn, axis);
 }
 
@@ -964,7 +981,7 @@ static orc_obj* mk_triangle(const double p[9], const double n[9], const double u
 }
 int orc_add_triangle_v(orc_scene* s, const double p[9], const double n[9], const double uv[6], int mat, int flip, int to_lights)
 { return finish_add(s, mk_triangle(p, n, uv, mat), flip, to_lights); }
-int orc_add_triangle_p(orc_scene* s, const double p[9], int mat, int flip, int to_lights)      /* polygon.hpp:54-80 */
+static orc_obj* mk_triangle_p(const double p[9], int mat)                                        /* polygon.hpp:54-80 */
 {
     v3 p0 = V(p[0], p[1], p[2]), p1 = V(p[3], p[4], p[5]), p2 = V(p[6], p[7], p[8]);
     v3 n0 = vnorm(vcross(vsub(p1, p0), vsub(p2, p0)));
@@ -972,8 +989,10 @@ int orc_add_triangle_p(orc_scene* s, const double p[9], int mat, int flip, int t
     v3 n2 = vnorm(vcross(vsub(p0, p2), vsub(p1, p2)));
     double n[9] = { n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z };
     double uv[6] = { p0.x, p0.y, p1.x, p1.y, p2.x, p2.y };
-    return finish_add(s, mk_triangle(p, n, uv, mat), flip, to_lights);
+    return mk_triangle(p, n, uv, mat);
 }
+int orc_add_triangle_p(orc_scene* s, const double p[9], int mat, int flip, int to_lights)
+{ return finish_add(s, mk_triangle_p(p, mat), flip, to_lights); }
 /* bulk add from flattened records (layout of include/rtcore.h): used by bench.py's cpu_baseline leg to time the oracle
  * on a scene the host mirror built.  Triangle corners are rebuilt as p0, p0+e1, p0+e2 (bounding boxes may differ from
  * the loader's by an ulp: good enough for a timing baseline, not used by the parity tests). */
@@ -1268,6 +1287,111 @@ orc_scene* orc_build_smoke(int width, int height, unsigned seed)
     return s;
 }
 
+/* ---- the `nested` fixture: wrappers nested every way the reference's object model allows (transform.hpp:9-149 compose freely), volumes
+ * around boxes (primitive.hpp:332-343 takes any object*), groups used as objects (group.hpp:12,68-102), an instance inside an instance.
+ * Same scene, same construction order as ref_harness.cpp build_nested and raytracing_amd/host/demo.hpp nested_test(). */
+static orc_obj* reg_leaf(orc_scene* s, orc_obj* o) { o->id = s->n_prims; push(&s->prims, &s->n_prims, &s->cap_prims, o); return o; }
+static orc_obj* mk_sphere(orc_scene* s, v3 c, double radius, int mat)
+{ orc_obj* o = new_obj(ORC_SPHERE); o->mat = mat; o->g[0] = c.x; o->g[1] = c.y; o->g[2] = c.z; o->g[3] = radius; return o; }
+static orc_obj* mk_box(v3 mn, v3 mx, int mat)
+{ orc_obj* o = new_obj(ORC_BOX); o->mat = mat; o->g[0] = mn.x; o->g[1] = mn.y; o->g[2] = mn.z; o->g[3] = mx.x; o->g[4] = mx.y; o->g[5] = mx.z; o->g[6] = 0; o->g[7] = 1; return o; }
+static orc_obj* mk_plane(int kind, double a0, double a1, double b0, double b1, double k, int mat)
+{ orc_obj* o = new_obj(kind); o->mat = mat; o->g[0] = a0; o->g[1] = a1; o->g[2] = b0; o->g[3] = b1; o->g[4] = k; return o; }
+static orc_obj* mk_flip(orc_obj* inner) { orc_obj* o = new_obj(O_FLIP); o->l = inner; o->mat = inner->mat; return o; }
+static orc_obj* mk_volume(orc_obj* surface, double density, int fog_mat)          /* primitive.hpp:332-344 */
+{ orc_obj* o = new_obj(ORC_VOLUME); o->l = surface; o->mat = fog_mat; o->g[4] = -1.0 / density; return o; }
+static orc_obj* mk_group(int n, orc_obj** items)
+{
+    orc_obj* o = new_obj(O_GROUP);
+    o->items = (orc_obj**) malloc(sizeof(orc_obj*) * n); o->n_items = n;
+    memcpy(o->items, items, sizeof(orc_obj*) * n);
+    return o;
+}
+static orc_obj* mk_bvh(orc_scene* s, int n, orc_obj** items, double start, double end)   /* new bvh(group): the builder permutes a copy */
+{
+    orc_obj** tmp = (orc_obj**) malloc(sizeof(orc_obj*) * n);
+    memcpy(tmp, items, sizeof(orc_obj*) * n);
+    orc_obj* b = bvh_build(&s->rng, tmp, 0, n, start, end);
+    free(tmp);
+    return b;
+}
+static void add_obj(orc_scene* s, orc_obj* o) { push(&s->objects, &s->n_objects, &s->cap_objects, o); }
+static int lam(orc_scene* s, double r, double g, double b) { return orc_mat_lambertian(s, orc_tex_constant(s, r, g, b)); }
+
+orc_scene* orc_build_nested(int width, int height, unsigned seed)
+{
+    orc_scene* s = orc_scene_new(width, height, seed);
+    s->wrapper_rows = 1;
+    /* 0 ground, 1 lamp */
+    add_obj(s, reg_leaf(s, mk_plane(ORC_PLANEXZ, -40, 40, -40, 40, 0, lam(s, 0.5, 0.5, 0.5))));
+    { orc_obj* lamp = reg_leaf(s, mk_plane(ORC_PLANEXZ, -4, 4, -4, 4, 14, orc_mat_emissive(s, orc_tex_constant(s, 8, 8, 8)))); add_obj(s, mk_flip(lamp)); }
+    /* 2 translate(translate(sphere)) */
+    add_obj(s, mk_translate(mk_translate(reg_leaf(s, mk_sphere(s, V(0, 1, 0), 1, lam(s, 0.8, 0.3, 0.3))), V(-6, 0, 0)), V(0, 0, -3)));
+    /* 3 translate(rotatey(rotatey(box))) */
+    add_obj(s, mk_translate(mk_rotatey(mk_rotatey(reg_leaf(s, mk_box(V(-1, 0, -1), V(1, 2, 1), lam(s, 0.3, 0.8, 0.3))), 20), 25), V(-2, 0, 4)));
+    /* 4 translate(rotatey(translate(rotatey(sphere)))), glass */
+    add_obj(s, mk_translate(mk_rotatey(mk_translate(mk_rotatey(reg_leaf(s, mk_sphere(s, V(0, 1, 0), 1, orc_mat_dielectric(s, 1.5))), 30), V(3, 0, 0)), 40), V(2, 0, -6)));
+    /* 5 rotatey(translate(sphere)), metal */
+    add_obj(s, mk_rotatey(mk_translate(reg_leaf(s, mk_sphere(s, V(0, 1.2, 0), 1.2, orc_mat_metal(s, orc_tex_constant(s, 0.8, 0.8, 0.6), 0.1))), V(7, 0, 0)), 50));
+    /* 6 volume(box) */
+    add_obj(s, reg_leaf(s, mk_volume(mk_box(V(-9, 0, 2), V(-6, 3, 5), orc_mat_dielectric(s, 1.5)), 0.4, orc_mat_fog(s, orc_tex_constant(s, 0.9, 0.9, 0.9)))));
+    /* 7 volume(translate(rotatey(box))) */
+    add_obj(s, reg_leaf(s, mk_volume(mk_translate(mk_rotatey(mk_box(V(0, 0, 0), V(2.5, 3, 2.5), orc_mat_dielectric(s, 1.5)), -18), V(5, 0, 3)), 0.5,
+                                     orc_mat_fog(s, orc_tex_constant(s, 0.2, 0.4, 0.9)))));
+    /* 8 translate(volume(sphere)) */
+    add_obj(s, mk_translate(reg_leaf(s, mk_volume(mk_sphere(s, V(0, 1.5, 0), 1.5, orc_mat_dielectric(s, 1.5)), 0.6, orc_mat_fog(s, orc_tex_constant(s, 0.9, 0.5, 0.2)))), V(-3, 0, -8)));
+    /* 9-11 a group as an object */
+    {
+        double tri[9] = { -12, 0, -4, -9, 0, -4, -10.5, 3, -4.5 };
+        orc_obj* m[3];
+        m[0] = reg_leaf(s, mk_sphere(s, V(-10, 1, -6), 1, lam(s, 0.7, 0.7, 0.2)));
+        m[1] = reg_leaf(s, mk_triangle_p(tri, lam(s, 0.2, 0.7, 0.7)));
+        m[2] = reg_leaf(s, mk_box(V(-13, 0, -9), V(-11, 2, -7), lam(s, 0.7, 0.2, 0.7)));
+        add_obj(s, mk_group(3, m));
+    }
+    /* 12-13 translate(group) */
+    {
+        orc_obj* m[2];
+        m[0] = reg_leaf(s, mk_sphere(s, V(0, 1, 0), 1, lam(s, 0.9, 0.6, 0.3)));
+        m[1] = reg_leaf(s, mk_sphere(s, V(2.2, 1, 0), 1, orc_mat_metal(s, orc_tex_constant(s, 0.9, 0.9, 0.9), 0.0)));
+        add_obj(s, mk_translate(mk_group(2, m), V(8, 0, -9)));
+    }
+    /* 14-18 an instance inside an instance: translate(rotatey(bvh{ sphere, translate(bvh{3 spheres}), sphere })) */
+    {
+        orc_obj* in[3];
+        in[0] = reg_leaf(s, mk_sphere(s, V(0, 0.6, 0), 0.6, lam(s, 0.9, 0.2, 0.2)));
+        in[1] = reg_leaf(s, mk_sphere(s, V(1.5, 0.6, 0), 0.6, lam(s, 0.2, 0.9, 0.2)));
+        in[2] = reg_leaf(s, mk_sphere(s, V(0, 0.6, 1.5), 0.6, lam(s, 0.2, 0.2, 0.9)));
+        orc_obj* inner = mk_bvh(s, 3, in, 0, 0);
+        orc_obj* mid[3];
+        mid[0] = reg_leaf(s, mk_sphere(s, V(-2, 1, 0), 1, lam(s, 0.6, 0.6, 0.6)));
+        mid[1] = mk_translate(inner, V(0, 2.2, 0));
+        mid[2] = reg_leaf(s, mk_sphere(s, V(2.5, 1, 1), 1, orc_mat_dielectric(s, 1.5)));
+        add_obj(s, mk_translate(mk_rotatey(mk_bvh(s, 3, mid, 0, 0), 35), V(-9, 0, 9)));
+    }
+    /* 19 flip(translate(sphere)): the flip counts.  20 translate(flip(sphere)): translate's set_face_normal overwrites it */
+    add_obj(s, mk_flip(mk_translate(reg_leaf(s, mk_sphere(s, V(0, 1, 0), 1, orc_mat_dielectric(s, 1.5))), V(4, 0, 8))));
+    add_obj(s, mk_translate(mk_flip(reg_leaf(s, mk_sphere(s, V(0, 1, 0), 1, orc_mat_dielectric(s, 1.5)))), V(7, 0, 7)));
+    /* 21-22 flip(bvh{sphere, rect}) */
+    {
+        orc_obj* m[2];
+        m[0] = reg_leaf(s, mk_sphere(s, V(11, 1, 2), 1, orc_mat_dielectric(s, 1.5)));
+        m[1] = reg_leaf(s, mk_plane(ORC_PLANEXY, 9, 13, 0, 3, 0, lam(s, 0.4, 0.4, 0.8)));
+        add_obj(s, mk_flip(mk_bvh(s, 2, m, 0, 0)));
+    }
+    /* 23 translate(msphere) */
+    {
+        orc_obj* o = new_obj(ORC_MSPHERE); o->mat = lam(s, 0.7, 0.3, 0.1);
+        o->g[0] = 0; o->g[1] = 1; o->g[2] = 0; o->g[3] = 0; o->g[4] = 1.5; o->g[5] = 0; o->g[6] = 0; o->g[7] = 1; o->g[8] = 0.8;
+        add_obj(s, mk_translate(reg_leaf(s, o), V(-5, 0, 6)));
+    }
+    orc_add_plane(s, ORC_PLANEXZ, -4, 4, -4, 4, 14, orc_mat_emissive(s, orc_tex_constant(s, 8, 8, 8)), 1, 1);
+    double pos[3] = { 2, 9, 26 }, at[3] = { 0, 1, 0 }, up[3] = { 0, 1, 0 };
+    orc_set_camera(s, pos, at, up, 40, 0.1, 25, 0, 1);
+    orc_build_bvh(s);
+    return s;
+}
+
 /* ------------------------------------------------------------------ pre-order view */
 static int pre_walk(orc_scene* s, const orc_obj* o, int* cap)
 {
@@ -1335,6 +1459,16 @@ static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int lef
     }
     r[1] = flipped;
     double* g = r + 4; double* m = r + 30;
+    if (s->wrapper_rows) {                                              /* ref_harness.cpp tree_dump::rows under g_wrapper_rows */
+        double code = 0, sum = 0; int i = 1;
+        for (const orc_obj* w = o; w->kind == O_FLIP || w->kind == O_TRANSLATE || w->kind == O_ROTATEY; w = w->l, i++) {
+            code = code * 4 + (w->kind == O_FLIP ? 1 : w->kind == O_ROTATEY ? 2 : 3);
+            if (w->kind == O_TRANSLATE) sum += i * (w->g[0] + 2 * w->g[1] + 3 * w->g[2]);
+            if (w->kind == O_ROTATEY) sum += i * (w->g[0] + 2 * w->g[1]);
+        }
+        r[28] = code; r[29] = sum;
+    }
+    if (base->kind == O_GROUP) { r[0] = 9; g[0] = base->n_items; return; }
     if (base->kind == O_BVH) {
         r[0] = 0;
         g[0] = base->box.mn.x; g[1] = base->box.mn.y; g[2] = base->box.mn.z;
@@ -1349,7 +1483,19 @@ static void put_obj_row(const orc_scene* s, const orc_obj* o, double* r, int lef
     if (base->kind == ORC_BOX) {                                        /* ref_harness.cpp tree_dump::rows, K_BOX */
         aabb bb; obj_bbox(o, 0, 0, &bb);
         r[3] = base->g[11];
+        if (xf) { r[3] = xf; g[6] = sn; g[7] = cs; g[8] = target.x; g[9] = target.y; g[10] = target.z; }   /* wrapper OBJECTS around the box: the innermost of each kind, as unwrap() keeps them */
         g[11] = bb.mn.x; g[12] = bb.mn.y; g[13] = bb.mn.z; g[14] = bb.mx.x; g[15] = bb.mx.y; g[16] = bb.mx.z;
+    }
+    if (base->kind == ORC_VOLUME) {                                     /* K_VOLUME: the boundary sphere's fields if it is one, neg_inv_d */
+        const orc_obj* b = base->l;
+        for (int k = 0; k < 4; k++) g[k] = 0;
+        if (b->kind == ORC_SPHERE) for (int k = 0; k < 4; k++) g[k] = b->g[k];
+        if (s->wrapper_rows) {
+            double code = 0;
+            while (b->kind == O_FLIP || b->kind == O_TRANSLATE || b->kind == O_ROTATEY) { code = code * 4 + (b->kind == O_FLIP ? 1 : b->kind == O_ROTATEY ? 2 : 3); b = b->l; }
+            g[5] = code * 16 + (b->kind == ORC_SPHERE ? 1 : b->kind == ORC_BOX ? 7 : 0);
+            if (b->kind == ORC_BOX) for (int k = 0; k < 6; k++) g[6 + k] = b->g[k];
+        }
     }
     if (base->mat >= 0) put_mat_row(s, base->mat, m);
 }
@@ -1392,30 +1538,107 @@ void orc_camera_fields(const orc_scene* s, double out[24])
 }
 
 /* ------------------------------------------------------------------ flattened export */
-/* one walk serves the counts (all outputs NULL) and the export.  A bvh (or leaf) wrapped in translate(rotatey(.)), rotatey(.) or
- * translate(.) becomes an instance: its nodes and leaves keep their object-space geometry and name the transform. */
-typedef struct { double* bbox; int32_t* child; double* xform_data; int32_t* node_xform; int32_t* prim_xform; int next, n_xf, cur; } exp_ctx;
+/* One walk serves the counts (all outputs NULL) and the export, in the layout of include/rtcore.h.
+ *   translate / rotatey around anything become instance transforms: the members keep their object-space geometry and name a CHAIN of
+ *     records, outermost first.  One record holds translate(rotatey(.)), rotatey(.) or translate(.): a rotatey joins the record before
+ *     it when that one holds a lone translate; every other wrapper opens a new record.
+ *   a box takes the innermost record into its own fields (RT_PRIM_FLAG_ROTATEY / _TRANSLATE), as cornell_box()'s boxes always did;
+ *   a flip counts only where no translate / rotatey lies outside it -- their set_face_normal calls overwrite `frontward`
+ *     (transform.hpp:25, 105) -- and reaches the leaves below it as RT_PRIM_FLAG_FLIP (no chain) or RT_PRIM_FLAG_FLIP_OUTER;
+ *   a group used as an object becomes group links (nodes with an inverted box): link(m0, link(m1, ...));
+ *   a volume's boundary is a sphere or a box inside translate(rotatey(.)). */
+typedef struct { int fl; double sn, cs; v3 t; } exp_level;
+typedef struct {
+    double* bbox; int32_t* child; double* xform_data; int32_t* node_xform; int32_t* prim_xform; int32_t* prim_flags; double* prim_data;
+    int next, n_xf, cur;                 /* cur: first record of the current chain once written, -1: not yet */
+    exp_level chain[32]; int n_chain;
+    int flip;                            /* parity of the flips that count */
+} exp_ctx;
+
+static int chain_records(exp_ctx* c)
+{
+    if (c->n_chain == 0) return -1;
+    if (c->cur >= 0) return c->cur;
+    c->cur = c->n_xf;
+    for (int k = 0; k < c->n_chain; k++) {
+        const exp_level* l = &c->chain[k];
+        if (c->xform_data) {
+            double* x = c->xform_data + 6 * c->n_xf;
+            x[0] = (l->fl & 2) ? l->sn : 0.0; x[1] = (l->fl & 2) ? l->cs : 1.0; x[2] = l->t.x; x[3] = l->t.y; x[4] = l->t.z;
+            x[5] = l->fl | (k + 1 < c->n_chain ? 8 : 0);
+        }
+        c->n_xf++;
+    }
+    return c->cur;
+}
+
+static int export_node(const orc_obj* o, exp_ctx* c);
+static int export_group(orc_obj* const* items, int n, exp_ctx* c)      /* link(m0, link(m1, ... link(mk-1, mk))) */
+{
+    if (n == 1) return export_node(items[0], c);
+    int idx = c->next++;
+    if (c->bbox) { double* b = c->bbox + 6 * idx; b[0] = b[1] = b[2] = ORC_INF; b[3] = b[4] = b[5] = -ORC_INF; }
+    if (c->node_xform) c->node_xform[idx] = -1;
+    int l = export_node(items[0], c);
+    int r = export_group(items + 1, n - 1, c);
+    if (c->child) { c->child[2 * idx] = l; c->child[2 * idx + 1] = r; }
+    return idx;
+}
+
 static int export_node(const orc_obj* o, exp_ctx* c)
 {
-    if (o->kind == O_TRANSLATE || o->kind == O_ROTATEY) {
-        int fl = 0; double sn = 0, cs = 1; v3 target = V(0, 0, 0);
-        if (o->kind == O_TRANSLATE) { target = V(o->g[0], o->g[1], o->g[2]); fl |= 4; o = o->l; }
-        if (o->kind == O_ROTATEY) { sn = o->g[0]; cs = o->g[1]; fl |= 2; o = o->l; }
-        if (o->kind == O_TRANSLATE || o->kind == O_ROTATEY || c->cur >= 0) { fprintf(stderr, "oracle export: only translate(rotatey(x)) nesting, one level\n"); abort(); }
-        int id = c->n_xf++;
-        if (c->xform_data) { double* x = c->xform_data + 6 * id; x[0] = sn; x[1] = cs; x[2] = target.x; x[3] = target.y; x[4] = target.z; x[5] = fl; }
-        c->cur = id;
-        int code = export_node(o, c);
-        c->cur = -1;
+    if (o->kind == O_FLIP && o->id < 0) {                              /* (a flip registered as the primitive itself is a leaf: export_prim unwraps it) */
+        const int counts = c->n_chain == 0;
+        if (counts) c->flip ^= 1;
+        int code = export_node(o->l, c);
+        if (counts) c->flip ^= 1;
         return code;
     }
-    if (o->kind != O_BVH) {
-        if (c->prim_xform && c->cur >= 0) c->prim_xform[o->id] = c->cur;
+    if (o->kind == O_TRANSLATE || o->kind == O_ROTATEY) {
+        const exp_ctx saved = *c;
+        exp_level* last = c->n_chain ? &c->chain[c->n_chain - 1] : NULL;
+        if (o->kind == O_ROTATEY && last && last->fl == 4) { last->fl |= 2; last->sn = o->g[0]; last->cs = o->g[1]; }
+        else {
+            if (c->n_chain == 32) { fprintf(stderr, "oracle export: more than 32 transform records in one chain\n"); abort(); }
+            exp_level* l = &c->chain[c->n_chain++];
+            memset(l, 0, sizeof *l); l->cs = 1;
+            if (o->kind == O_TRANSLATE) { l->fl = 4; l->t = V(o->g[0], o->g[1], o->g[2]); }
+            else { l->fl = 2; l->sn = o->g[0]; l->cs = o->g[1]; }
+        }
+        c->cur = -1;
+        int code = export_node(o->l, c);
+        const int next = c->next, n_xf = c->n_xf;
+        *c = saved; c->next = next; c->n_xf = n_xf;
+        return code;
+    }
+    if (o->kind == O_GROUP) {
+        if (o->n_items == 0) { fprintf(stderr, "oracle export: empty group\n"); abort(); }
+        return export_group(o->items, o->n_items, c);
+    }
+    if (o->kind != O_BVH) {                                             /* a leaf */
+        const orc_obj* base = o;
+        while (base->kind == O_FLIP) base = base->l;
+        int extra = 0, n_chain = c->n_chain, cur = c->cur;
+        if (base->kind == ORC_BOX && n_chain > 0 && ((int) base->g[11] & 6) == 0) {   /* the innermost record moves into the box */
+            const exp_level* l = &c->chain[n_chain - 1];
+            extra |= l->fl;
+            if (c->prim_data) {
+                double* d = c->prim_data + (size_t) o->id * ORC_PRIM_STRIDE;
+                d[6] = (l->fl & 2) ? l->sn : 0.0; d[7] = (l->fl & 2) ? l->cs : 1.0; d[8] = l->t.x; d[9] = l->t.y; d[10] = l->t.z;
+            }
+            c->n_chain--; c->cur = -1;
+        }
+        const int xi = chain_records(c);
+        if (c->n_chain != n_chain) { c->n_chain = n_chain; c->cur = cur; }
+        if (c->flip) extra |= xi >= 0 ? 16 : 1;
+        if (c->prim_xform && xi >= 0) c->prim_xform[o->id] = xi;
+        if (c->prim_flags) c->prim_flags[o->id] |= extra;
         return ~o->id;
     }
     int idx = c->next++;
     if (c->bbox) { put3(c->bbox + 6 * idx, o->box.mn); put3(c->bbox + 6 * idx + 3, o->box.mx); }
-    if (c->node_xform) c->node_xform[idx] = c->cur;
+    const int xi = chain_records(c);
+    if (c->node_xform) c->node_xform[idx] = xi;
     int l = export_node(o->l, c);
     int r = o->r == o->l ? l : export_node(o->r, c);                  /* span 1 (bvh.hpp:31-34): the same child twice */
     if (c->child) { c->child[2 * idx] = l; c->child[2 * idx + 1] = r; }
@@ -1428,7 +1651,7 @@ void orc_export_counts(const orc_scene* s, int32_t c[8])
     c[0] = x.next; c[1] = s->n_prims; c[2] = s->n_mats; c[3] = s->n_texs; c[4] = s->n_lights; c[5] = s->n_objects;
     c[6] = s->n_pixel_bytes; c[7] = x.n_xf;
 }
-/* instance transforms of the flattened scene: xform_data n_xforms x 6 (sin, cos, target, wrappers), node_xform / prim_xform -1 = none */
+/* instance transforms of the flattened scene: xform_data n_xforms x 6 (sin, cos, target, flags), node_xform / prim_xform -1 = none */
 void orc_export_instances(const orc_scene* s, double* xform_data, int32_t* node_xform, int32_t* prim_xform)
 {
     int32_t c[8]; orc_export_counts(s, c);
@@ -1445,6 +1668,21 @@ static void export_prim(const orc_obj* o, int32_t* kind, int32_t* flags, int32_t
     memset(data, 0, sizeof(double) * ORC_PRIM_STRIDE);
     memcpy(data, base->g, sizeof(double) * ORC_PRIM_STRIDE);
     if (base->kind == ORC_BOX) { *flags |= (int) base->g[11]; data[11] = 0; }   /* wrappers travel as RT_PRIM_FLAG_ROTATEY / _TRANSLATE */
+    if (base->kind == ORC_VOLUME) {                                     /* the boundary: a sphere, or a box inside translate(rotatey(.)) */
+        const orc_obj* b = base->l;
+        int fl = 0; double sn = 0, cs = 1; v3 target = V(0, 0, 0);
+        while (b->kind == O_FLIP) b = b->l;
+        if (b->kind == O_TRANSLATE) { target = V(b->g[0], b->g[1], b->g[2]); fl |= 4; b = b->l; while (b->kind == O_FLIP) b = b->l; }
+        if (b->kind == O_ROTATEY) { sn = b->g[0]; cs = b->g[1]; fl |= 2; b = b->l; while (b->kind == O_FLIP) b = b->l; }
+        memset(data, 0, sizeof(double) * ORC_PRIM_STRIDE);
+        if (b->kind == ORC_SPHERE && fl == 0) { for (int k = 0; k < 4; k++) data[k] = b->g[k]; data[4] = base->g[4]; }
+        else if (b->kind == ORC_BOX && ((int) b->g[11] & 6) == 0) {
+            for (int k = 0; k < 6; k++) data[k] = b->g[k];
+            data[6] = sn; data[7] = cs; data[8] = target.x; data[9] = target.y; data[10] = target.z; data[11] = base->g[4];
+            *flags |= 8 | fl;
+        }
+        else { fprintf(stderr, "oracle export: a volume's boundary must be a sphere or a box inside translate(rotatey(.))\n"); abort(); }
+    }
 }
 void orc_export(const orc_scene* s, double* node_bbox, int32_t* node_child, int32_t* roots,
                 int32_t* prim_kind, int32_t* prim_flags, int32_t* prim_mat, double* prim_data,
@@ -1452,9 +1690,9 @@ void orc_export(const orc_scene* s, double* node_bbox, int32_t* node_child, int3
                 int32_t* tex_kind, double* tex_data, uint8_t* tex_pixels,
                 int32_t* light_kind, int32_t* light_flags, int32_t* light_mat, double* light_data, double cam[24])
 {
-    exp_ctx x; memset(&x, 0, sizeof x); x.cur = -1; x.bbox = node_bbox; x.child = node_child;
-    for (int i = 0; i < s->n_objects; i++) roots[i] = export_node(s->objects[i], &x);
     for (int i = 0; i < s->n_prims; i++) export_prim(s->prims[i], prim_kind + i, prim_flags + i, prim_mat + i, prim_data + (size_t) i * ORC_PRIM_STRIDE);
+    exp_ctx x; memset(&x, 0, sizeof x); x.cur = -1; x.bbox = node_bbox; x.child = node_child; x.prim_flags = prim_flags; x.prim_data = prim_data;
+    for (int i = 0; i < s->n_objects; i++) roots[i] = export_node(s->objects[i], &x);
     for (int i = 0; i < s->n_mats; i++) { mat_kind[i] = s->mats[i].kind; mat_tex[i] = s->mats[i].tex; memcpy(mat_data + i * ORC_MAT_STRIDE, s->mats[i].d, sizeof(double) * ORC_MAT_STRIDE); }
     for (int i = 0; i < s->n_texs; i++) { tex_kind[i] = s->texs[i].kind; memcpy(tex_data + i * ORC_TEX_STRIDE, s->texs[i].d, sizeof(double) * ORC_TEX_STRIDE); }
     if (s->n_pixel_bytes) memcpy(tex_pixels, s->pixels, s->n_pixel_bytes);

@@ -338,7 +338,7 @@ template <typename R> __device__ inline bool tri_t(const Prim<R>& p, const Ray<R
 // tested in the constructor's order through group::intersect's shrinking t_max (group.hpp:68-83), and the record comes back
 // out through both wrappers' set_face_normal calls.  h == nullptr: distance only.
 template <typename R> struct Hit;
-template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h);
+template <typename R, bool kSelf = true> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h);
 
 // A ray that starts ON a sphere has the roots t = 0 and t = -2 (oc.d)/(d.d) exactly.  In fp64 the reference's t = 0
 // root comes out ~1e-16 and is cut by t_min = 1e-3; in fp32 the origin is only within ~1e-7 of the surface, and at
@@ -381,17 +381,50 @@ template <> __device__ inline bool volume_crossings<float>(const Prim<float>& p,
     t1 = fminf(r0, r1); t2 = fmaxf(r0, r1);
     return t2 >= t1 + 0.0001f;
 }
-template <typename R> __device__ inline bool volume_t(const Prim<R>& p, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
+// ... around a box boundary (RT_PRIM_FLAG_BOUNDARY_BOX; the box optionally inside rotatey and translate, which box_t applies): the same
+// two calls of the boundary's intersect(), group::intersect over the six rects each time (primitive.hpp:439-442)
+template <typename R> __device__ inline bool volume_crossings_box(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R& t1, R& t2)
+{
+    if (!box_t<R, false>(p, aux, r, -rt_inf<R>(), rt_inf<R>(), t1, nullptr)) return false;        // :349
+    return box_t<R, false>(p, aux, r, t1 + R(0.0001), rt_inf<R>(), t2, nullptr);                  // :353
+}
+// fp32: entry and exit of the slabs in the box's frame from one pass (t1 + 0.0001 is t1 itself for distant boxes, as with the sphere)
+template <> __device__ inline bool volume_crossings_box<float>(const Prim<float>& p, const TriShade<float>& aux, const Ray<float>& r, float& t1, float& t2)
+{
+    const int fl = p.flags();
+    vec3<float> o = r.o, d = r.d;
+    if (fl & RT_PRIM_FLAG_TRANSLATE) o = o - vec3<float>(aux.n[0], aux.n[1], aux.n[2]);
+    if (fl & RT_PRIM_FLAG_ROTATEY) {
+        const float sn = p.g[6], cs = p.g[7];
+        const float ox = cs * o.x - sn * o.z, oz = sn * o.x + cs * o.z, dx = cs * d.x - sn * d.z, dz = sn * d.x + cs * d.z;
+        o.x = ox; o.z = oz; d.x = dx; d.z = dz;
+    }
+    const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+    float t_in = -rt_inf<float>(), t_out = rt_inf<float>();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float lo = p.g[k], hi = p.g[3 + k];
+        if (dd[k] == 0.0f) { if (oo[k] < lo || oo[k] > hi) return false; continue; }
+        const float inv = 1.0f / dd[k], a = (lo - oo[k]) * inv, b = (hi - oo[k]) * inv;
+        t_in = fmaxf(t_in, fminf(a, b)); t_out = fminf(t_out, fmaxf(a, b));
+    }
+    t1 = t_in; t2 = t_out;
+    return t2 >= t1 + 0.0001f;
+}
+template <typename R> __device__ inline bool volume_t(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
 {
     R t1, t2;
-    if (!g || !volume_crossings(p, r, t1, t2)) return false;           // no stream (first-hit entry points): a volume is never hit
+    if (!g) return false;                                              // no stream (first-hit entry points): a volume is never hit
+    const bool boxed = (p.flags() & RT_PRIM_FLAG_BOUNDARY_BOX) != 0;
+    if (boxed ? !volume_crossings_box(p, aux[p.id], r, t1, t2) : !volume_crossings(p, r, t1, t2)) return false;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
     if (t1 < R(0)) t1 = R(0);
     const R ray_length = length(r.d);
     const R inner_length = (t2 - t1) * ray_length;
-    const R intersect_distance = p.g[4] * rt_log(uniform<R>(*g));
+    const R neg_inv_d = boxed ? p.g[8] : p.g[4];
+    const R intersect_distance = neg_inv_d * rt_log(uniform<R>(*g));
     if (intersect_distance > inner_length) return false;
     t = t1 + intersect_distance / ray_length;
     return true;
@@ -408,6 +441,19 @@ template <typename R> __device__ inline void xform_rays(const Xform<R>& x, const
         rr.o.z = x.sn * tr.o.x + x.cs * tr.o.z;
         rr.d.x = x.cs * tr.d.x - x.sn * tr.d.z;
         rr.d.z = x.sn * tr.d.x + x.cs * tr.d.z;
+    }
+}
+
+// ray into the frame at the inner end of the transform chain that starts at record xi (rtcore.h RT_XFORM_FLAG_CHAIN: wrappers that do not
+// fit one translate(rotatey(.)) record, instances inside instances), outermost wrapper first as the reference's intersect() calls nest
+template <typename R> __device__ inline void chain_ray(const Xform<R>* __restrict__ xs, int xi, const Ray<R>& r, Ray<R>& out)
+{
+    Ray<R> tr;
+    xform_rays(xs[xi], r, tr, out);
+    while (xs[xi].flags & RT_XFORM_FLAG_CHAIN) {
+        xi++;
+        const Ray<R> cur = out;
+        xform_rays(xs[xi], cur, tr, out);
     }
 }
 
@@ -445,7 +491,7 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const P
     }
     case RT_PRIM_TRIANGLE: if constexpr (!class_no_tri(kFull)) return tri_t(p, r, t_min, t_max, t, a, b); else return false;
     case RT_PRIM_BOX: if constexpr (class_boxes(kFull)) return box_t<R>(p, aux[p.id], r, t_min, t_max, t, nullptr); else return false;
-    case RT_PRIM_VOLUME: if constexpr (class_boxes(kFull)) return volume_t<R>(p, r, t_min, t_max, t, g); else return false;
+    case RT_PRIM_VOLUME: if constexpr (class_boxes(kFull)) return volume_t<R>(p, aux, r, t_min, t_max, t, g); else return false;
     default: return plane_t(p, r, t_min, t_max, t, a, b);
     }
 }
@@ -465,8 +511,8 @@ template <typename R, int kFull = 2> __device__ inline bool prim_t(const Prim<R>
 {
     const int xi = class_instances(kFull) ? p.xform() : -1;
     if (class_instances(kFull) && xi >= 0) {
-        Ray<R> tr, rr;
-        xform_rays(aux.xforms[xi], r, tr, rr);
+        Ray<R> rr;
+        chain_ray(aux.xforms, xi, r, rr);
         return prim_t_local<R, kFull>(p, aux, rr, t_min, t_max, t, g);
     }
     return prim_t_local<R, kFull>(p, aux, r, t_min, t_max, t, g);
@@ -558,27 +604,36 @@ template <typename R, int kFull = 2> __device__ inline void fill_record(const Pr
 {
     const int xi = class_instances(kFull) ? p.xform() : -1;
     if (!class_instances(kFull) || xi < 0) { fill_record_local<R, kFull>(p, tris, r, t, need_uv, h); return; }
-    // member of an instance: the record is made in the instance's frame and comes back out through both wrappers' set_face_normal
-    const Xform<R>& x = tris.xforms[xi];
-    Ray<R> tr, rr;
-    xform_rays(x, r, tr, rr);
-    fill_record_local<R, kFull>(p, tris, rr, t, need_uv, h);
-    if (x.flags & RT_PRIM_FLAG_ROTATEY) {                                   // transform.hpp:99-110
-        vec3<R> position = h.pos, normal = h.normal;
-        position.x = x.cs * h.pos.x + x.sn * h.pos.z;
-        position.z = -x.sn * h.pos.x + x.cs * h.pos.z;
-        normal.x = x.cs * h.normal.x + x.sn * h.normal.z;
-        normal.z = -x.sn * h.normal.x + x.cs * h.normal.z;
-        h.pos = position;
-        set_face_normal(h, rr, normal);
+    // member of an instance: the record is made in the innermost frame and comes back out through every wrapper's set_face_normal, innermost
+    // first -- each with the ray as THAT wrapper saw it (transform.hpp:25-27, 99-110), so the rays are rebuilt from the outside for every level
+    // (chains are one record long for translate(rotatey(.)); longer ones are rare and short)
+    const Xform<R>* __restrict__ xs = tris.xforms;
+    int n = 1;
+    while (xs[xi + n - 1].flags & RT_XFORM_FLAG_CHAIN) n++;
+    for (int level = n - 1; level >= 0; level--) {
+        Ray<R> cur = r, tr, rr;
+        for (int k = 0; k < level; k++) { Ray<R> a; const Ray<R> c = cur; xform_rays(xs[xi + k], c, a, cur); }
+        xform_rays(xs[xi + level], cur, tr, rr);
+        if (level == n - 1) fill_record_local<R, kFull>(p, tris, rr, t, need_uv, h);
+        const Xform<R>& x = xs[xi + level];
+        if (x.flags & RT_PRIM_FLAG_ROTATEY) {                                   // transform.hpp:99-110
+            vec3<R> position = h.pos, normal = h.normal;
+            position.x = x.cs * h.pos.x + x.sn * h.pos.z;
+            position.z = -x.sn * h.pos.x + x.cs * h.pos.z;
+            normal.x = x.cs * h.normal.x + x.sn * h.normal.z;
+            normal.z = -x.sn * h.normal.x + x.cs * h.normal.z;
+            h.pos = position;
+            set_face_normal(h, rr, normal);
+        }
+        if (x.flags & RT_PRIM_FLAG_TRANSLATE) {                                 // transform.hpp:25-27
+            h.pos = h.pos + vec3<R>(x.t[0], x.t[1], x.t[2]);
+            set_face_normal(h, tr, h.normal);
+        }
     }
-    if (x.flags & RT_PRIM_FLAG_TRANSLATE) {                                 // transform.hpp:25-27
-        h.pos = h.pos + vec3<R>(x.t[0], x.t[1], x.t[2]);
-        set_face_normal(h, tr, h.normal);
-    }
+    if (p.flags() & RT_PRIM_FLAG_FLIP_OUTER) h.front = !h.front;                // a flip outside the whole chain (transform.hpp:134)
 }
 
-template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h)
+template <typename R, bool kSelf> __device__ inline bool box_t(const Prim<R>& p, const TriShade<R>& aux, const Ray<R>& r, R t_min, R t_max, R& t, Hit<R>* h)
 {
     const int fl = p.flags();
     const vec3<R> target(aux.n[0], aux.n[1], aux.n[2]);
@@ -604,7 +659,7 @@ template <typename R> __device__ inline bool box_t(const Prim<R>& p, const TriSh
     // fp32: a ray that starts on this box must not find the side it starts on (its t = 0 root drifts past t_min at grazing
     // angles), but it must find the others: the wrappers' set_face_normal calls (object-space ray against the world-space
     // normal) can turn the shading normal into the box, and the reference then traces the path inside it.
-    const bool self = sizeof(R) == sizeof(float) && p.id == r.from;
+    const bool self = kSelf && sizeof(R) == sizeof(float) && p.id == r.from;     // (kSelf false: the box is a volume's boundary)
     R closest = t_max;
     int hit_side = -1;
     Prim<R> s;
@@ -699,7 +754,7 @@ __device__ inline int closest_hit(const Op<R>* __restrict__ ops, int n_ops, cons
             if (kStats) st->n_box++;
             bool inside;
             if (op.prim == -1) inside = box_hit(op, r, t_min, closest);
-            else { Ray<R> tr, rr; xform_rays(aux.xforms[-2 - op.prim], r, tr, rr); inside = box_hit(op, rr, t_min, closest); }
+            else { Ray<R> rr; chain_ray(aux.xforms, -2 - op.prim, r, rr); inside = box_hit(op, rr, t_min, closest); }
             i = inside ? i + 1 : op.skip;
         }
         else {

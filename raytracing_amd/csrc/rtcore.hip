@@ -155,21 +155,29 @@ int validate(const rt_scene_desc* d)
     for (int i = 0; i < d->n_prims; i++) {
         if (d->prim_kind[i] < RT_PRIM_SPHERE || d->prim_kind[i] > RT_PRIM_VOLUME) return fail(RT_EINVAL, "unknown primitive kind");
         if (d->prim_mat[i] < 0 || d->prim_mat[i] >= d->n_mats) return fail(RT_EINVAL, "primitive material index out of range");
-        if (d->prim_kind[i] == RT_PRIM_VOLUME && (d->mat_kind[d->prim_mat[i]] != RT_MAT_FOG || d->prim_flags[i] != 0))
-            return fail(RT_EINVAL, "a volume takes a fog material and no wrapper flags (primitive.hpp:332-344)");
+        const int fl = d->prim_flags[i];
+        if (fl & ~(RT_PRIM_FLAG_FLIP | RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE | RT_PRIM_FLAG_BOUNDARY_BOX | RT_PRIM_FLAG_FLIP_OUTER)) return fail(RT_EINVAL, "unknown primitive flag");
+        if (d->prim_kind[i] == RT_PRIM_VOLUME) {
+            if (d->mat_kind[d->prim_mat[i]] != RT_MAT_FOG) return fail(RT_EINVAL, "a volume takes a fog material (primitive.hpp:332-344)");
+            if ((fl & (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE)) && !(fl & RT_PRIM_FLAG_BOUNDARY_BOX))
+                return fail(RT_EINVAL, "a volume's rotatey / translate flags describe its boundary BOX (RT_PRIM_FLAG_BOUNDARY_BOX)");
+        }
+        else if (fl & RT_PRIM_FLAG_BOUNDARY_BOX) return fail(RT_EINVAL, "RT_PRIM_FLAG_BOUNDARY_BOX is a flag of RT_PRIM_VOLUME");
+        if ((fl & (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE)) && d->prim_kind[i] != RT_PRIM_BOX && d->prim_kind[i] != RT_PRIM_VOLUME)
+            return fail(RT_EINVAL, "only a box (or a volume's boundary box) carries rotatey / translate in its own record: use prim_xform");
     }
     if (d->n_xforms < 0 || d->n_xforms > 65534 || (d->n_xforms && (!d->xform_data || !d->prim_xform || (d->n_nodes && !d->node_xform))))
         return fail(RT_EINVAL, "instance transforms: 0..65534 of them, with xform_data, node_xform and prim_xform present");
     for (int i = 0; i < d->n_xforms; i++) {
         const int fl = (int) d->xform_data[(size_t) i * RT_XFORM_STRIDE + 5];
-        if (fl == 0 || (fl & ~(RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE))) return fail(RT_EINVAL, "instance transform: wrappers must be ROTATEY and / or TRANSLATE");
+        if ((fl & (RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE)) == 0 || (fl & ~(RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE | RT_XFORM_FLAG_CHAIN)))
+            return fail(RT_EINVAL, "instance transform: wrappers must be ROTATEY and / or TRANSLATE (plus RT_XFORM_FLAG_CHAIN)");
+        if ((fl & RT_XFORM_FLAG_CHAIN) && i + 1 == d->n_xforms) return fail(RT_EINVAL, "instance transform: the last record cannot continue (RT_XFORM_FLAG_CHAIN)");
     }
     if (d->n_xforms) {
         for (int i = 0; i < d->n_nodes; i++) if (d->node_xform[i] < -1 || d->node_xform[i] >= d->n_xforms) return fail(RT_EINVAL, "node_xform out of range");
         for (int i = 0; i < d->n_prims; i++) {
             if (d->prim_xform[i] < -1 || d->prim_xform[i] >= d->n_xforms) return fail(RT_EINVAL, "prim_xform out of range");
-            if (d->prim_xform[i] >= 0 && (d->prim_kind[i] == RT_PRIM_BOX || d->prim_kind[i] == RT_PRIM_VOLUME))
-                return fail(RT_EINVAL, "a box carries its wrappers in its own record, a volume takes none: prim_xform must be -1");
         }
     }
     for (int i = 0; i < d->n_lights; i++) {
@@ -222,10 +230,15 @@ int linearize(const rt_scene_desc* d, Flat& f)
                 stack.pop_back();
                 continue;
             }
+            // a group link (rtcore.h: inverted box) has no box test and therefore no entry: its children follow one another, the running t_max
+            // of the walk is group::intersect's `closest` (group.hpp:72-80)
+            const bool link = d->node_bbox[(size_t) fr.code * 6] > d->node_bbox[(size_t) fr.code * 6 + 3];
             if (fr.stage == 0) {
-                fr.op = (int) f.op_prim.size();
-                f.op_prim.push_back(d->n_xforms && d->node_xform[fr.code] >= 0 ? -2 - d->node_xform[fr.code] : -1); f.op_skip.push_back(0);   // see rt_device.h closest_hit
-                for (int k = 0; k < 6; k++) f.op_box.push_back(d->node_bbox[(size_t) fr.code * 6 + k]);
+                fr.op = link ? -1 : (int) f.op_prim.size();
+                if (!link) {
+                    f.op_prim.push_back(d->n_xforms && d->node_xform[fr.code] >= 0 ? -2 - d->node_xform[fr.code] : -1); f.op_skip.push_back(0);   // see rt_device.h closest_hit
+                    for (int k = 0; k < 6; k++) f.op_box.push_back(d->node_bbox[(size_t) fr.code * 6 + k]);
+                }
                 fr.stage = 1;
                 int32_t child = d->node_child[(size_t) fr.code * 2];
                 stack.push_back({ child, 0, -1 });
@@ -236,7 +249,7 @@ int linearize(const rt_scene_desc* d, Flat& f)
                 stack.push_back({ child, 0, -1 });
             }
             else {
-                f.op_skip[fr.op] = (int32_t) f.op_prim.size();
+                if (fr.op >= 0) f.op_skip[fr.op] = (int32_t) f.op_prim.size();
                 stack.pop_back();
             }
             if (f.op_prim.size() > guard) return fail(RT_EINVAL, "bvh links are not a tree (shared node or cycle)");
@@ -249,11 +262,15 @@ template <typename R> void fill_prim(rt::Prim<R>& p, rt::TriShade<R>* tri, int k
 {
     std::memset(&p, 0, sizeof p);
     p.kf = (int32_t) ((uint32_t) kind | ((uint32_t) (flags & 0xff) << 8) | ((uint32_t) (xform + 1) << 16)); p.mat = mat; p.id = id;
-    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_VOLUME ? 5 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : kind == RT_PRIM_BOX ? 8 : 5;
+    const bool boxed = kind == RT_PRIM_BOX || (kind == RT_PRIM_VOLUME && (flags & RT_PRIM_FLAG_BOUNDARY_BOX));
+    int n = kind == RT_PRIM_SPHERE ? 4 : kind == RT_PRIM_VOLUME ? 5 : kind == RT_PRIM_MSPHERE ? 9 : kind == RT_PRIM_TRIANGLE ? 9 : 5;
+    if (boxed) n = 8;
     for (int k = 0; k < n; k++) p.g[k] = (R) g[k];
+    if (boxed && !(flags & RT_PRIM_FLAG_ROTATEY)) { p.g[6] = R(0); p.g[7] = R(1); }
+    if (kind == RT_PRIM_VOLUME && boxed) p.g[8] = (R) g[11];                             // neg_inv_d behind the boundary box's fields
     if (tri) {
         std::memset(tri, 0, sizeof *tri);
-        if (kind == RT_PRIM_BOX) for (int k = 0; k < 3; k++) tri->n[k] = (R) g[8 + k];   // translate target
+        if (boxed) for (int k = 0; k < 3; k++) tri->n[k] = (flags & RT_PRIM_FLAG_TRANSLATE) ? (R) g[8 + k] : R(0);   // translate target
         if (kind == RT_PRIM_TRIANGLE) {
             for (int k = 0; k < 9; k++) tri->n[k] = (R) g[9 + k];
             for (int k = 0; k < 6; k++) tri->uv[k] = (R) g[18 + k];
@@ -267,7 +284,9 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
     const double* g = d->prim_data + (size_t) i * RT_PRIM_STRIDE;
     auto sphere = [&](const double c[3], double r) { double lo[3] = { c[0] - r, c[1] - r, c[2] - r }, hi[3] = { c[0] + r, c[1] + r, c[2] + r }; b.grow(lo); b.grow(hi); };
     switch (d->prim_kind[i]) {
-    case RT_PRIM_SPHERE: case RT_PRIM_VOLUME: sphere(g, std::fabs(g[3])); break;
+    case RT_PRIM_VOLUME: if (d->prim_flags[i] & RT_PRIM_FLAG_BOUNDARY_BOX) goto as_box;
+        // fall through
+    case RT_PRIM_SPHERE: sphere(g, std::fabs(g[3])); break;
     case RT_PRIM_MSPHERE: {
         double t0 = std::min(std::min(d->camera[22], d->camera[23]), std::min(g[6], 0.0));
         double t1 = std::max(std::max(d->camera[22], d->camera[23]), std::max(g[7], 0.0));
@@ -279,7 +298,7 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
         }
         break;
     }
-    case RT_PRIM_BOX: {   // the eight corners, out of the box's frame: rotatey (transform.hpp:60-66) then translate
+    case RT_PRIM_BOX: as_box: {   // the eight corners, out of the box's frame: rotatey (transform.hpp:60-66) then translate
         const int fl = d->prim_flags[i];
         const double sn = (fl & RT_PRIM_FLAG_ROTATEY) ? g[6] : 0.0, cs = (fl & RT_PRIM_FLAG_ROTATEY) ? g[7] : 1.0;
         for (int c = 0; c < 8; c++) {
@@ -306,18 +325,23 @@ void prim_bounds(const rt_scene_desc* d, int i, rtb::Box& b)
         break;
     }
     }
-    if (d->n_xforms && d->prim_xform[i] >= 0) {   // member of an instance: the eight corners of its own box, out of the instance's frame
-        const double* x = d->xform_data + (size_t) d->prim_xform[i] * RT_XFORM_STRIDE;
-        const int fl = (int) x[5];
-        const double sn = (fl & RT_PRIM_FLAG_ROTATEY) ? x[0] : 0.0, cs = (fl & RT_PRIM_FLAG_ROTATEY) ? x[1] : 1.0;
-        rtb::Box w;
-        for (int c = 0; c < 8; c++) {
-            const double px = (c & 1) ? b.hi[0] : b.lo[0], py = (c & 2) ? b.hi[1] : b.lo[1], pz = (c & 4) ? b.hi[2] : b.lo[2];
-            double p[3] = { cs * px + sn * pz, py, -sn * px + cs * pz };
-            if (fl & RT_PRIM_FLAG_TRANSLATE) for (int k = 0; k < 3; k++) p[k] += x[2 + k];
-            w.grow(p);
+    if (d->n_xforms && d->prim_xform[i] >= 0) {   // member of an instance: the eight corners of its own box, out of the instance's frame --
+        // through every record of the chain, innermost (the last) first
+        int first = d->prim_xform[i], last = first;
+        while ((int) d->xform_data[(size_t) last * RT_XFORM_STRIDE + 5] & RT_XFORM_FLAG_CHAIN) last++;
+        for (int xi = last; xi >= first; xi--) {
+            const double* x = d->xform_data + (size_t) xi * RT_XFORM_STRIDE;
+            const int fl = (int) x[5];
+            const double sn = (fl & RT_PRIM_FLAG_ROTATEY) ? x[0] : 0.0, cs = (fl & RT_PRIM_FLAG_ROTATEY) ? x[1] : 1.0;
+            rtb::Box w;
+            for (int c = 0; c < 8; c++) {
+                const double px = (c & 1) ? b.hi[0] : b.lo[0], py = (c & 2) ? b.hi[1] : b.lo[1], pz = (c & 4) ? b.hi[2] : b.lo[2];
+                double p[3] = { cs * px + sn * pz, py, -sn * px + cs * pz };
+                if (fl & RT_PRIM_FLAG_TRANSLATE) for (int k = 0; k < 3; k++) p[k] += x[2 + k];
+                w.grow(p);
+            }
+            b = w;
         }
-        b = w;
     }
     // Pad flat boxes (rects, axis-aligned triangles: zero extent along one axis).  The boxes only cull and are rounded outward to fp32
     // afterwards, so the pad need not be the reference's (primitive.hpp:203 0.001, polygon.hpp:128 1e-7): it was 1e-4, a twentieth of an
@@ -452,7 +476,8 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         ops[i].skip = f.op_skip[i]; ops[i].prim = f.op_prim[i];
     }
     bool has_tri = false;
-    for (int i = 0; i < d->n_prims; i++) has_tri |= d->prim_kind[i] == RT_PRIM_TRIANGLE || d->prim_kind[i] == RT_PRIM_BOX;   // kinds with a side record
+    for (int i = 0; i < d->n_prims; i++) has_tri |= d->prim_kind[i] == RT_PRIM_TRIANGLE || d->prim_kind[i] == RT_PRIM_BOX ||
+                                                    (d->prim_kind[i] == RT_PRIM_VOLUME && (d->prim_flags[i] & RT_PRIM_FLAG_BOUNDARY_BOX));   // kinds with a side record
     bool light_tri = false;
     for (int i = 0; i < d->n_lights; i++) light_tri |= d->light_kind[i] == RT_PRIM_TRIANGLE || d->light_kind[i] == RT_PRIM_BOX;
 

@@ -79,39 +79,67 @@ private:
     }
 };
 
-// ---- flattener traversal (needs the complete bvh / group types)
-// the bvh under o's translate / rotatey wrappers, or null when o is not an instance of a sub-tree
-static inline const bvh* instanced_bvh(const object* o, flat_xform& x)
-{
-    const object* in = o;
-    while (const object* next = in->peel_transform(x)) in = next;
-    return in != o ? dynamic_cast<const bvh*>(in) : nullptr;
-}
-
+// ---- flattener traversal (needs the complete bvh / group types; the wrappers speak through object::wrapped)
 inline void flattener::collect(const object* o)
 {
-    { flat_xform x; if (const bvh* nested = instanced_bvh(o, x)) { collect(nested); return; } }
+    flat_wrapper w;
+    while (const object* inner = o->wrapped(w)) o = inner;
     if (const bvh* b = dynamic_cast<const bvh*>(o)) { collect(b->left); if (b->right != b->left) collect(b->right); return; }
     if (const group* g = dynamic_cast<const group*>(o)) { for (int i = 0; i < g->size(); i++) collect(g->content()[i]); return; }
     leaves.push_back(std::make_pair(o->serial, o));
 }
 
+// a group used as an object (group.hpp:68-83): link(m0, link(m1, ... link(mk-1, mk))), a group of one is its member
+inline int32_t flattener::emit_group(object* const* items, int n)
+{
+    if (n == 1) return emit(items[0]);
+    int32_t idx = (int32_t) (out.node_child.size() / 2);
+    out.node_child.push_back(0); out.node_child.push_back(0);
+    out.node_xform.push_back(-1);
+    for (int k = 0; k < 3; k++) out.node_bbox.push_back(infinity);             // inverted box: no box test (rtcore.h)
+    for (int k = 0; k < 3; k++) out.node_bbox.push_back(-infinity);
+    int32_t l = emit(items[0]);
+    int32_t r = emit_group(items + 1, n - 1);
+    out.node_child[(size_t) idx * 2] = l;
+    out.node_child[(size_t) idx * 2 + 1] = r;
+    return idx;
+}
+
 inline int32_t flattener::emit(const object* o)
 {
-    {
-        flat_xform x;
-        if (const bvh* nested = instanced_bvh(o, x)) {       // translate(rotatey(bvh)): the sub-tree stays in its own frame
-            if (cur_xform >= 0) throw std::runtime_error("flatten: an instance inside an instance is not supported");
-            cur_xform = xform_id(x);
-            int32_t code = emit(nested);
-            cur_xform = -1;
+    flat_wrapper w;
+    if (const object* inner = o->wrapped(w)) {
+        if (w.kind == flat_wrapper::flip) {                  // counts only where no translate / rotatey lies outside it
+            const bool counts = chain.empty();
+            if (counts) flip_parity ^= 1;
+            int32_t code = emit(inner);
+            if (counts) flip_parity ^= 1;
             return code;
         }
+        const std::vector<flat_xform> saved = chain;
+        const int saved_first = chain_first;
+        if (w.kind == flat_wrapper::rotatey && !chain.empty() && chain.back().flags == RT_PRIM_FLAG_TRANSLATE) {
+            chain.back().flags |= RT_PRIM_FLAG_ROTATEY; chain.back().sin_theta = w.sin_theta; chain.back().cos_theta = w.cos_theta;
+        }
+        else {
+            flat_xform x;
+            if (w.kind == flat_wrapper::translate) { x.flags = RT_PRIM_FLAG_TRANSLATE; for (int k = 0; k < 3; k++) x.target[k] = w.target[k]; }
+            else { x.flags = RT_PRIM_FLAG_ROTATEY; x.sin_theta = w.sin_theta; x.cos_theta = w.cos_theta; }
+            chain.push_back(x);
+        }
+        chain_first = -1;
+        int32_t code = emit(inner);
+        chain = saved; chain_first = saved_first;
+        return code;
+    }
+    if (const group* g = dynamic_cast<const group*>(o)) {
+        if (g->size() == 0) throw std::runtime_error("flatten: an empty group inside the scene");
+        return emit_group(g->content(), g->size());
     }
     if (const bvh* b = dynamic_cast<const bvh*>(o)) {
         int32_t idx = (int32_t) (out.node_child.size() / 2);
         out.node_child.push_back(0); out.node_child.push_back(0);
-        out.node_xform.push_back(cur_xform);
+        out.node_xform.push_back(chain_records());           // an instanced sub-tree stays in its own frame
         for (int k = 0; k < 3; k++) out.node_bbox.push_back(b->bbox.min()[k]);
         for (int k = 0; k < 3; k++) out.node_bbox.push_back(b->bbox.max()[k]);
         int32_t l = emit(b->left);
@@ -121,13 +149,22 @@ inline int32_t flattener::emit(const object* o)
         return idx;
     }
     flat_leaf leaf;
-    if (!o->leaf_record(leaf)) throw std::runtime_error("flatten: object type is not supported inside a bvh (nested group / unknown class)");
+    if (!o->leaf_record(leaf)) throw std::runtime_error("flatten: object type is not supported inside a scene (unknown class)");
     int id = prim_ids.at(o);
-    store_prim(id, leaf);
-    if (leaf.xform.flags) {
-        if (cur_xform >= 0) throw std::runtime_error("flatten: a wrapped primitive inside an instance is not supported");
-        out.prim_xform[id] = xform_id(leaf.xform);
+    const std::vector<flat_xform> saved = chain;
+    const int saved_first = chain_first;
+    if (leaf.kind == RT_PRIM_BOX && !chain.empty()) {        // the innermost record moves into the box's own fields
+        const flat_xform& x = chain.back();
+        leaf.flags |= x.flags;
+        const bool rot = (x.flags & RT_PRIM_FLAG_ROTATEY) != 0;
+        leaf.data[6] = rot ? x.sin_theta : 0.0; leaf.data[7] = rot ? x.cos_theta : 1.0;
+        for (int k = 0; k < 3; k++) leaf.data[8 + k] = x.target[k];
+        chain.pop_back(); chain_first = -1;
     }
-    else out.prim_xform[id] = cur_xform;
+    const int xi = chain_records();
+    if (chain.size() != saved.size()) { chain = saved; chain_first = saved_first; }
+    if (flip_parity) leaf.flags |= xi >= 0 ? RT_PRIM_FLAG_FLIP_OUTER : RT_PRIM_FLAG_FLIP;
+    store_prim(id, leaf);
+    out.prim_xform[id] = xi;
     return ~id;
 }

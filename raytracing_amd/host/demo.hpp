@@ -217,3 +217,56 @@ inline group cornell_box()
 {
     return demo_parts::assemble(demo_parts::cornell_palette, 5, demo_parts::cornell_parts, 8);
 }
+
+// What the object model composes and the reference's demos never do (no counterpart in demo.hpp; the same scene as oracle/ref_harness.cpp
+// build_nested, which builds it from the reference's own classes): wrappers nested every way (transform.hpp:9-149), volumes around boxes
+// (primitive.hpp:332-343), groups used as objects (group.hpp:12,68-102), an instance inside an instance.  Leaves in this order are the
+// fixture's primitive ids.
+inline group nested_test()
+{
+    group grp;
+    grp.add(new planexz(-40, 40, -40, 40, 0, new lambertian(vec3d(0.5, 0.5, 0.5))));
+    grp.add(new flip(new planexz(-4, 4, -4, 4, 14, new emissive(vec3d(8, 8, 8)))));
+    grp.add(new translate(new translate(new sphere(vec3d(0, 1, 0), 1, new lambertian(vec3d(0.8, 0.3, 0.3))), vec3d(-6, 0, 0)), vec3d(0, 0, -3)));
+    grp.add(new translate(new rotatey(new rotatey(new box(vec3d(-1, 0, -1), vec3d(1, 2, 1), new lambertian(vec3d(0.3, 0.8, 0.3))), 20), 25), vec3d(-2, 0, 4)));
+    grp.add(new translate(new rotatey(new translate(new rotatey(new sphere(vec3d(0, 1, 0), 1, new dielectric(1.5)), 30), vec3d(3, 0, 0)), 40), vec3d(2, 0, -6)));
+    grp.add(new rotatey(new translate(new sphere(vec3d(0, 1.2, 0), 1.2, new metal(vec3d(0.8, 0.8, 0.6), 0.1)), vec3d(7, 0, 0)), 50));
+    grp.add(new volume(new box(vec3d(-9, 0, 2), vec3d(-6, 3, 5), new dielectric(1.5)), 0.4, vec3d(0.9, 0.9, 0.9)));
+    grp.add(new volume(new translate(new rotatey(new box(vec3d(0, 0, 0), vec3d(2.5, 3, 2.5), new dielectric(1.5)), -18), vec3d(5, 0, 3)), 0.5, vec3d(0.2, 0.4, 0.9)));
+    grp.add(new translate(new volume(new sphere(vec3d(0, 1.5, 0), 1.5, new dielectric(1.5)), 0.6, vec3d(0.9, 0.5, 0.2)), vec3d(-3, 0, -8)));
+    {
+        group* sub = new group();
+        sub->add(new sphere(vec3d(-10, 1, -6), 1, new lambertian(vec3d(0.7, 0.7, 0.2))));
+        sub->add(new triangle(vec3d(-12, 0, -4), vec3d(-9, 0, -4), vec3d(-10.5, 3, -4.5), new lambertian(vec3d(0.2, 0.7, 0.7))));
+        sub->add(new box(vec3d(-13, 0, -9), vec3d(-11, 2, -7), new lambertian(vec3d(0.7, 0.2, 0.7))));
+        grp.add(sub);
+    }
+    {
+        group* sub = new group();
+        sub->add(new sphere(vec3d(0, 1, 0), 1, new lambertian(vec3d(0.9, 0.6, 0.3))));
+        sub->add(new sphere(vec3d(2.2, 1, 0), 1, new metal(vec3d(0.9, 0.9, 0.9), 0.0)));
+        grp.add(new translate(sub, vec3d(8, 0, -9)));
+    }
+    {
+        group in;
+        in.add(new sphere(vec3d(0, 0.6, 0), 0.6, new lambertian(vec3d(0.9, 0.2, 0.2))));
+        in.add(new sphere(vec3d(1.5, 0.6, 0), 0.6, new lambertian(vec3d(0.2, 0.9, 0.2))));
+        in.add(new sphere(vec3d(0, 0.6, 1.5), 0.6, new lambertian(vec3d(0.2, 0.2, 0.9))));
+        object* inner = new bvh(in);
+        group mid;
+        mid.add(new sphere(vec3d(-2, 1, 0), 1, new lambertian(vec3d(0.6, 0.6, 0.6))));
+        mid.add(new translate(inner, vec3d(0, 2.2, 0)));
+        mid.add(new sphere(vec3d(2.5, 1, 1), 1, new dielectric(1.5)));
+        grp.add(new translate(new rotatey(new bvh(mid), 35), vec3d(-9, 0, 9)));
+    }
+    grp.add(new flip(new translate(new sphere(vec3d(0, 1, 0), 1, new dielectric(1.5)), vec3d(4, 0, 8))));
+    grp.add(new translate(new flip(new sphere(vec3d(0, 1, 0), 1, new dielectric(1.5))), vec3d(7, 0, 7)));
+    {
+        group m;
+        m.add(new sphere(vec3d(11, 1, 2), 1, new dielectric(1.5)));
+        m.add(new planexy(9, 13, 0, 3, 0, new lambertian(vec3d(0.4, 0.4, 0.8))));
+        grp.add(new flip(new bvh(m)));
+    }
+    grp.add(new translate(new msphere(vec3d(0, 1, 0), vec3d(0, 1.5, 0), 0, 1, 0.8, new lambertian(vec3d(0.7, 0.3, 0.1))), vec3d(-5, 0, 6)));
+    return grp;
+}

@@ -48,9 +48,16 @@ struct flat_scene {
     }
 };
 
-// rotatey / translate wrappers peeled off an object (reference: src/cpp/transform.hpp:9-121); translate is the outer one
+// one record of an instance transform (rtcore.h xform_data): translate(rotatey(.)), rotatey(.) or translate(.); translate is the outer one
 struct flat_xform {
     int flags = 0;                          // RT_PRIM_FLAG_ROTATEY | RT_PRIM_FLAG_TRANSLATE
+    double sin_theta = 0, cos_theta = 1, target[3] = { 0, 0, 0 };
+};
+
+// one wrapper object as object::wrapped() describes it (reference: src/cpp/transform.hpp:9-149)
+struct flat_wrapper {
+    enum { none = 0, flip = 1, rotatey = 2, translate = 3 };
+    int kind = none;
     double sin_theta = 0, cos_theta = 1, target[3] = { 0, 0, 0 };
 };
 
@@ -59,7 +66,6 @@ struct flat_leaf {
     int kind = 0, flags = 0;
     const material* mat = nullptr;
     double data[RT_PRIM_STRIDE] = { 0 };
-    flat_xform xform;                       // wrappers around a leaf that does not carry them in its own record (anything but a box)
 };
 
 class flattener {
@@ -69,9 +75,17 @@ public:
     int texture_id(const texture* t);     // defined in texture.hpp
     int material_id(const material* m);   // defined in material.hpp
 
-    // pass 1: collect leaves (so ids can follow construction order); pass 2: emit nodes
-    void collect(const object* o);        // defined in bvh.hpp
-    int32_t emit(const object* o);        // defined in bvh.hpp: returns the child code of o
+    // pass 1: collect leaves (so ids can follow construction order); pass 2: emit nodes.  Both are defined in bvh.hpp.
+    //   translate / rotatey around anything become instance transforms: the members keep their object-space geometry and name a CHAIN of
+    //     records (rtcore.h RT_XFORM_FLAG_CHAIN), outermost first.  One record holds translate(rotatey(.)), rotatey(.) or translate(.): a
+    //     rotatey joins the record before it when that one holds a lone translate; every other wrapper opens a new record;
+    //   a box takes the innermost record into its own fields (RT_PRIM_FLAG_ROTATEY / _TRANSLATE), as cornell_box()'s boxes do;
+    //   a flip counts only where no translate / rotatey lies outside it -- their set_face_normal calls overwrite `frontward`
+    //     (transform.hpp:25, 105) -- and reaches the leaves below it as RT_PRIM_FLAG_FLIP (no chain) or RT_PRIM_FLAG_FLIP_OUTER;
+    //   a group used as an object becomes group links (nodes with an inverted box): link(m0, link(m1, ...)).
+    void collect(const object* o);
+    int32_t emit(const object* o);        // returns the child code of o
+    int32_t emit_group(object* const* items, int n);
 
     void assign_prim_ids()
     {
@@ -82,13 +96,24 @@ public:
         out.prim_data.assign(leaves.size() * RT_PRIM_STRIDE, 0.0);
         out.prim_xform.assign(leaves.size(), -1);
     }
-    int xform_id(const flat_xform& x)
+    // the records of the current chain, written once per distinct chain: index of the first, -1 for no wrapper
+    int chain_records()
     {
-        const double rec[RT_XFORM_STRIDE] = { x.sin_theta, x.cos_theta, x.target[0], x.target[1], x.target[2], (double) x.flags };
-        out.xform_data.insert(out.xform_data.end(), rec, rec + RT_XFORM_STRIDE);
-        return (int) (out.xform_data.size() / RT_XFORM_STRIDE) - 1;
+        if (chain.empty()) return -1;
+        if (chain_first >= 0) return chain_first;
+        chain_first = (int) (out.xform_data.size() / RT_XFORM_STRIDE);
+        for (size_t k = 0; k < chain.size(); k++) {
+            const flat_xform& x = chain[k];
+            const bool rot = (x.flags & RT_PRIM_FLAG_ROTATEY) != 0;
+            const double rec[RT_XFORM_STRIDE] = { rot ? x.sin_theta : 0.0, rot ? x.cos_theta : 1.0, x.target[0], x.target[1], x.target[2],
+                                                  (double) (x.flags | (k + 1 < chain.size() ? RT_XFORM_FLAG_CHAIN : 0)) };
+            out.xform_data.insert(out.xform_data.end(), rec, rec + RT_XFORM_STRIDE);
+        }
+        return chain_first;
     }
-    int cur_xform = -1;                     // the instance being emitted
+    std::vector<flat_xform> chain;          // the wrappers around the object being emitted, outermost first
+    int chain_first = -1;                   // first record of `chain` once written
+    int flip_parity = 0;                    // the flips that count
     void store_prim(int id, const flat_leaf& l)
     {
         out.prim_kind[id] = l.kind; out.prim_flags[id] = l.flags; out.prim_mat[id] = material_id(l.mat);

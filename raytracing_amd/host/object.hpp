@@ -12,6 +12,6 @@ public:
     virtual bool bounding_box(double start, double end, aabb& bbox) const = 0;
     // a leaf writes its record and returns true; containers (bvh, group) return false
     virtual bool leaf_record(flat_leaf& out) const { (void) out; return false; }
-    // translate / rotatey: add this wrapper to x and return the wrapped object; everything else returns null
-    virtual const object* peel_transform(flat_xform& x) const { (void) x; return nullptr; }
+    // flip / translate / rotatey: describe this wrapper in w and return the wrapped object; everything else returns null
+    virtual const object* wrapped(flat_wrapper& w) const { (void) w; return nullptr; }
 };

@@ -54,22 +54,16 @@ public:
     }
 };
 
-// constant-density medium inside `surface` (reference: src/cpp/primitive.hpp:329-396).  The core takes sphere boundaries
-// (what all_feature_test() builds, demo.hpp:125-130); the boundary's own material is never used by the reference either.
+class box;
+// constant-density medium inside `surface` (reference: src/cpp/primitive.hpp:329-396).  The core takes a sphere or a box as the boundary,
+// the box optionally inside rotatey and then translate (volume(translate(rotatey(box))), the smoke blocks of "the next week"); the
+// boundary's own material is never used by the reference either.  leaf_record is defined below `box`.
 class volume : public object {
 public:
     volume(object* surface_, double density, texture* tex) : surface(surface_), mat(new fog(tex)), neg_inv_d(-1.0 / density) {}
     volume(object* surface_, double density, const vec3d& color) : surface(surface_), mat(new fog(color)), neg_inv_d(-1.0 / density) {}
     bool bounding_box(double start, double end, aabb& bbox) const override { return surface->bounding_box(start, end, bbox); }
-    bool leaf_record(flat_leaf& out) const override
-    {
-        const sphere* s = dynamic_cast<const sphere*>(surface);
-        if (!s) throw std::runtime_error("volume: the boundary must be a sphere");
-        out.kind = RT_PRIM_VOLUME; out.mat = mat;
-        for (int k = 0; k < 3; k++) out.data[k] = s->center[k];
-        out.data[3] = s->radius; out.data[4] = neg_inv_d;
-        return true;
-    }
+    bool leaf_record(flat_leaf& out) const override;
 private:
     object* surface;
     material* mat;
@@ -131,3 +125,31 @@ public:
         return true;
     }
 };
+
+
+inline bool volume::leaf_record(flat_leaf& out) const
+{
+    out.kind = RT_PRIM_VOLUME; out.mat = mat;
+    // the boundary's wrappers, outermost first: flips do not matter to a medium, translate(rotatey(.)) goes into the record
+    const object* s = surface;
+    int fl = 0;
+    flat_wrapper w, rot, tr;
+    for (const object* in; (in = s->wrapped(w)) != nullptr; s = in) {
+        if (w.kind == flat_wrapper::translate && fl == 0) { tr = w; fl |= RT_PRIM_FLAG_TRANSLATE; }
+        else if (w.kind == flat_wrapper::rotatey && !(fl & RT_PRIM_FLAG_ROTATEY)) { rot = w; fl |= RT_PRIM_FLAG_ROTATEY; }
+        else if (w.kind != flat_wrapper::flip) throw std::runtime_error("volume: the boundary's wrappers must be translate(rotatey(.)), rotatey(.) or translate(.)");
+    }
+    if (const sphere* sp = dynamic_cast<const sphere*>(s)) {
+        if (fl) throw std::runtime_error("volume: a wrapped sphere as the boundary is not supported (wrap the volume instead)");
+        for (int k = 0; k < 3; k++) out.data[k] = sp->center[k];
+        out.data[3] = sp->radius; out.data[4] = neg_inv_d;
+        return true;
+    }
+    if (const box* b = dynamic_cast<const box*>(s)) {
+        out.flags |= RT_PRIM_FLAG_BOUNDARY_BOX | fl;
+        for (int k = 0; k < 3; k++) { out.data[k] = b->minimum[k]; out.data[3 + k] = b->maximum[k]; out.data[8 + k] = tr.target[k]; }
+        out.data[6] = rot.sin_theta; out.data[7] = rot.cos_theta; out.data[11] = neg_inv_d;
+        return true;
+    }
+    throw std::runtime_error("volume: the boundary must be a sphere or a box");
+}

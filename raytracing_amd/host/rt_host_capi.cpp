@@ -182,6 +182,21 @@ rth_scene* rth_build_features_lit(int width, int height, unsigned seed)
     catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
+// nested_test() (demo.hpp) under the light and camera of oracle/ref_harness.cpp build_nested
+rth_scene* rth_build_nested(int width, int height, unsigned seed)
+{
+    try {
+        srand(seed);
+        scene scn(width, height);
+        scn.add_object(nested_test());
+        scn.add_light(new flip(new planexz(-4, 4, -4, 4, 14, new emissive(vec3d(8, 8, 8)))));
+        scn.set_camera(camera(vec3d(2, 9, 26), vec3d(0, 1, 0), vec3d(0, 1, 0), 40, double(width) / height, 0.1, 25, 0, 1));
+        scn.build_bvh();
+        return finish(scn, width, height);
+    }
+    catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
 // volume / fog: smoke_scene() (demo.hpp) under its flipped rect light, camera of the classic final-scene view
 rth_scene* rth_build_smoke(int width, int height, unsigned seed)
 {

@@ -25,7 +25,7 @@ def load_host_library():
         L.rth_last_error.restype = C.c_char_p
         L.rth_build_random_spheres.restype = C.c_void_p
         L.rth_build_random_spheres.argtypes = [C.c_int, C.c_int, C.c_uint]
-        for name in ("rth_build_mixed", "rth_build_deep_bounce", "rth_build_textured", "rth_build_cornell", "rth_build_smoke", "rth_build_features", "rth_build_features_lit", "rth_build_instanced"):
+        for name in ("rth_build_mixed", "rth_build_deep_bounce", "rth_build_textured", "rth_build_cornell", "rth_build_smoke", "rth_build_features", "rth_build_features_lit", "rth_build_instanced", "rth_build_nested"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         L.rth_build_obj.restype = C.c_void_p
@@ -90,6 +90,11 @@ class HostScene:
     def instanced(cls, width, height, seed=1):
         """the Cornell room with instances and no medium: a turned and moved cloud of spheres under its own tree, a moved and a turned sphere"""
         return cls(load_host_library().rth_build_instanced(width, height, seed), width, height)
+
+    @classmethod
+    def nested(cls, width, height, seed=1):
+        """nested_test() (host/demo.hpp): wrappers nested every way, volumes around boxes, groups used as objects, an instance in an instance"""
+        return cls(load_host_library().rth_build_nested(width, height, seed), width, height)
 
     @classmethod
     def smoke(cls, width, height, seed=1):

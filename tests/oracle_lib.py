@@ -37,7 +37,8 @@ def lib():
         L.orc_build_smoke.restype = C.c_void_p
         L.orc_build_features.restype = C.c_void_p
         L.orc_build_features_lit.restype = C.c_void_p
-        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke", "orc_build_features", "orc_build_features_lit"):
+        L.orc_build_nested.restype = C.c_void_p
+        for name in ("orc_scene_new", "orc_build_c0", "orc_build_mixed", "orc_build_cornell", "orc_build_smoke", "orc_build_features", "orc_build_features_lit", "orc_build_nested"):
             getattr(L, name).argtypes = [C.c_int, C.c_int, C.c_uint]
         _lib = L
     return _lib
@@ -81,6 +82,11 @@ class Scene:
     def features_lit(cls, width, height, seed=1):
         """all_feature_test() under a flipped rect light just below the demo's own (which faces up)"""
         return cls(lib().orc_build_features_lit(width, height, seed), width, height)
+
+    @classmethod
+    def nested(cls, width, height, seed=1):
+        """wrappers nested every way, volumes around boxes, groups as objects, an instance inside an instance: ref_harness.cpp build_nested"""
+        return cls(lib().orc_build_nested(width, height, seed), width, height)
 
     @classmethod
     def cornell(cls, width, height, seed=1):

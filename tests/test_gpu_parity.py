@@ -25,7 +25,8 @@ SCENES = {
 # scenes with participating media: the free-flight draw sits inside the intersection test (primitive.hpp:373), so the first-hit
 # entry points (no random stream) do not apply; render tests do
 RENDER_SCENES = dict(SCENES, smoke=("smoke", lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
-                     features=("features", lambda gd, m: O.Scene.features(m["width"], m["height"], m["seed"])))
+                     features=("features", lambda gd, m: O.Scene.features(m["width"], m["height"], m["seed"])),
+                     nested=("nested", lambda gd, m: O.Scene.nested(m["width"], m["height"], m["seed"])))
 
 
 @pytest.fixture(scope="module")
@@ -108,6 +109,39 @@ def test_first_hit_all_feature_test_scene(R, golden_dir):
     osc.free()
 
 
+def test_first_hit_nested_wrappers_groups_and_instances(R, golden_dir):
+    """What the reference's object model composes and its demos never do (ref_harness.cpp build_nested): translate(translate(x)),
+    rotatey(rotatey(box)), rotatey(translate(x)), translate(rotatey(translate(rotatey(x)))), flips inside and outside wrappers and around a
+    bvh, a group as a bvh leaf and inside a translate, an instance inside an instance, a moving sphere inside a translate, volumes around
+    boxes.  The flattener turns the wrappers into chains of transform records and the groups into box-less links; the fixture names the
+    LEAF behind every hit (by the hit record's material).  Rays whose fixture hit is a volume are left out (the first-hit entry points
+    have no stream: a volume is never hit); on all others leaf, t bits and frontward flag are the real reference's, bit for bit.  Test
+    counts and visit hashes are not compared: the harness counts a wrapped subtree or a group as one leaf."""
+    tag, make = RENDER_SCENES["nested"]
+    g, m = load(golden_dir, "nested")
+    osc = make(golden_dir, m)
+    d = osc.export()
+    sc = R.Scene(d)
+    rays = g[tag + "_fh_rays"].reshape(-1, 7)
+    want = g[tag + "_fh_prim"]
+    kind = np.asarray(d["prim_kind"])
+    is_volume = (want >= 0) & (kind[np.maximum(want, 0)] == 8)
+    keep = ~is_volume
+    out = sc.first_hit(rays)
+    assert keep.sum() > 2000 and len(set(want[keep].tolist())) >= 20, "the fixture reaches (nearly) every leaf"
+    assert np.array_equal(out["prim"][keep], want[keep]), "leaf"
+    hit = keep & (want >= 0)
+    assert np.array_equal(out["t"][hit].view(np.uint64), g[tag + "_fh_t"][hit].view(np.uint64)), "t bits"
+    assert np.array_equal(out["front"][hit], g[tag + "_fh_front"][hit]), "frontward"
+    # every wrapper kind is exercised by a hit: chains of two records, box with its own record plus a chain, outer flip, group links
+    xf, fl = np.asarray(d["prim_xform"]), np.asarray(d["prim_flags"])
+    chained = [p for p in range(len(kind)) if xf[p] >= 0 and (int(d["xform_data"][xf[p], 5]) & 8)]
+    assert len(chained) >= 5 and all((want[hit] == p).sum() > 0 for p in chained)
+    assert any((want[hit] == p).sum() > 0 for p in range(len(kind)) if fl[p] & 16)
+    sc.destroy()
+    osc.free()
+
+
 def test_all_feature_test_scene_fast_mode(R, golden_dir):
     """The fast kernel's instance-aware variant (scenes with instance transforms run render_wave_kernel<.., kInst = true>) on
     all_feature_test(): volumes draw inside the traversal, so the fast tree's streams differ from the reference-order modes';
@@ -162,7 +196,7 @@ def test_fast_tree_returns_the_reference_hits(R, golden_dir, name):
 
 
 @pytest.mark.parametrize("qnodes", ["0", "1"])
-@pytest.mark.parametrize("name", ["c0_seed1", "c0_seed7", "mixed", "cornell", "obj", "ngon", "features", "smoke"])
+@pytest.mark.parametrize("name", ["c0_seed1", "c0_seed7", "mixed", "cornell", "obj", "ngon", "features", "smoke", "nested"])
 def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, monkeypatch, name, qnodes):
     """RT_MODE_FAST_FP64's traversal (rt_first_hit_tree: the library's SAH tree, fp32 box culling with the render kernel's own code,
     binary 64-byte nodes and quantised four-wide nodes, fp64 primitive tests in the reference's evaluation order) against the reference walk
@@ -198,9 +232,16 @@ def test_fast_fp64_first_hits_are_the_reference_hits_bit_for_bit(R, golden_dir, 
     kind = np.asarray(d["prim_kind"])
     with np.errstate(invalid="ignore"):
         msphere = diff & ~zero & (b["prim"] >= 0) & (kind[np.maximum(b["prim"], 0)] == 2) & ((a["prim"] < 0) | (b["t"] < a["t"]))
-    unexplained = diff & ~zero & ~tie & ~msphere
+    # in-plane: a ray that lies exactly IN the plane of a rect (direction component 0, origin on the plane: the fixture's lattice-aligned
+    # edge cases) gets t = 0/0 there, and the reference's range test lets NaN pass (primitive.hpp:180): whoever tests that rect "hits" it.
+    # The reference's walk only gets there through the rect's own box, the fast tree whenever the leaf's box is hit (a leaf holds up to
+    # four primitives).  Recognised by the NaN distance; measure zero for sampled rays
+    with np.errstate(invalid="ignore"):
+        inplane = diff & ~zero & np.isnan(b["t"]) & np.any(rays[:, 3:6] == 0, axis=1)
+    unexplained = diff & ~zero & ~tie & ~msphere & ~inplane
+    assert int(inplane.sum()) <= 2, int(inplane.sum())
     assert not unexplained.any(), [(int(i), rays[i].tolist(), int(a["prim"][i]), float(a["t"][i]), int(b["prim"][i]), float(b["t"][i])) for i in np.nonzero(unexplained)[0][:5]]
-    limits = {"features": (12, 0), "mixed": (0, 4), "smoke": (0, 6)}.get(name, (0, 0))      # measured: features 10 ties, mixed 2 / smoke 3 moving-sphere rays
+    limits = {"features": (12, 0), "mixed": (0, 4), "smoke": (0, 6), "nested": (4, 8)}.get(name, (0, 0))      # measured: features 10 ties, mixed 2 / smoke 3 moving-sphere rays
     print(f"[first hits through the fast tree] {name} qnodes={qnodes}: {int(diff.sum())} of {len(rays)} rays differ: ties {int(tie.sum())} (edge {int(edge.sum())}), zero-direction {int((diff & zero).sum())}, msphere {int(msphere.sum())}")
     assert int(tie.sum()) <= limits[0] and int(msphere.sum()) <= limits[1], (int(tie.sum()), int(msphere.sum()))
     assert int((~diff).sum()) >= len(rays) - 64
@@ -241,7 +282,7 @@ def test_render_fast_fp64_equals_reference_mode(R, golden_dir, name):
     osc.free()
 
 
-@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "cornell", "obj", "smoke", "features"])
+@pytest.mark.parametrize("name", ["c0_seed1", "mixed", "cornell", "obj", "smoke", "features", "nested"])
 def test_render_fp64_matches_oracle_same_streams(R, golden_dir, name):
     tag, make = RENDER_SCENES[name]
     g, m = load(golden_dir, name)
@@ -472,7 +513,7 @@ def test_depth_limited_tree_same_frame(R, golden_dir, monkeypatch):
     osc.free()
 
 
-@pytest.mark.parametrize("name", ["c0_seed1", "cornell", "smoke"])
+@pytest.mark.parametrize("name", ["c0_seed1", "cornell", "smoke", "nested"])
 def test_converged_image_matches_cpu_reference_independent_streams(R, golden_dir, name):
     """The north-star image check: a converged GPU render against a converged CPU render of the same scene and spp drawn from
     INDEPENDENT random streams (different seeds), so nothing but the estimator has to agree.  Tolerance: the relative RMSE

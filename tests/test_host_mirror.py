@@ -124,6 +124,26 @@ def test_host_scene_and_bvh_match_reference_fixture(golden_dir, name):
     hs.free()
 
 
+def test_nested_wrappers_groups_and_volume_boxes_flatten_like_the_oracle(golden_dir):
+    """nested_test() (host/demo.hpp) through scene::build_bvh and the flattener against the oracle's independent flatten of the same scene
+    (orc_build_nested, itself pinned bit for bit to the fixture of the real reference: tests/test_oracle_golden.py `nested`): same tree,
+    same primitive ids and records, same chains of transform records (translate(translate(.)), rotatey(translate(.)), an instance inside
+    an instance), the innermost record folded into a box, outer flips, group links, volumes around boxes."""
+    g = np.load(os.path.join(golden_dir, "nested.npz"))
+    m = {k: int(g["meta_" + k]) for k in ("width", "height", "seed")}
+    hs = HostScene.nested(m["width"], m["height"], m["seed"])
+    d = hs.arrays()
+    od = O.Scene.nested(m["width"], m["height"], m["seed"]).export()
+    for k in ("node_bbox", "prim_data", "light_data", "xform_data", "camera"):
+        assert np.array_equal(bits(d[k]), bits(od[k])), k
+    for k in ("node_child", "roots", "prim_kind", "prim_flags", "light_kind", "light_flags", "node_xform", "prim_xform"):
+        assert np.array_equal(d[k], od[k]), k
+    assert np.array_equal(bits(d["camera"]), bits(g["nested_camera"]))
+    fl, xf = np.asarray(d["prim_flags"]), np.asarray(d["xform_data"])
+    assert (fl & 16).any() and (fl & 8).any() and (xf[:, 5].astype(int) & 8).any() and np.isinf(d["node_bbox"]).any()
+    hs.free()
+
+
 def test_png_roundtrip(tmp_path):
     """image_io.hpp: write a PNG with the host writer, read it back with the host reader through an image texture."""
     import subprocess

@@ -35,6 +35,8 @@ SCENES = {
     "cornell": ("cornell", 48, lambda gd, m: O.Scene.cornell(m["width"], m["height"], m["seed"])),
     "smoke": ("smoke", 32, lambda gd, m: O.Scene.smoke(m["width"], m["height"], m["seed"])),
     "features": ("features", 32, lambda gd, m: O.Scene.features(m["width"], m["height"], m["seed"])),
+    # wrappers nested every way, volumes around boxes, groups used as objects, an instance inside an instance (ref_harness.cpp build_nested)
+    "nested": ("nested", 32, lambda gd, m: O.Scene.nested(m["width"], m["height"], m["seed"])),
     "obj": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "mesh_scene.obj"), m["width"], m["height"], m["seed"])),
     "ngon": ("obj", 32, lambda gd, m: O.obj_scene(os.path.join(gd, "ngon_scene.obj"), m["width"], m["height"], m["seed"])),
 }
@@ -73,6 +75,8 @@ def test_scene_bvh_firsthit_image(golden_dir, name):
     plain = hit & ~inst                                          # harness reports the wrapper, the oracle the sphere inside it
     assert np.array_equal(ids[fh["entry"][plain]], fh["prim"][plain])
     assert np.all(fh["prim"][inst] >= 0)
+    if tag + "_fh_prim" in g:      # the fixture names the LEAF behind every hit (by the hit record's material), also inside wrappers, groups, instances
+        assert np.array_equal(fh["prim"], g[tag + "_fh_prim"]), "leaf hit"
     # full render: trace (raytracing.cpp:30-70) + pixel loop / NaN rejection / tonemap (raytracing.cpp:96-123)
     total, rgb, counters = s.render(0, m["spp"], m["depth"], O.RNG_GLIBC)
     assert_bits(total * (1 / m["spp"]), g[tag + "_img_radiance"], "radiance")
