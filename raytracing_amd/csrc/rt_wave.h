@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
         const unsigned long long want = __ballot(!alive && !finished);
         const unsigned long long have = __ballot(alive);
         if (want && (have == 0 || __popcll(want) >= regen_min)) {
+            RT_ASM_MARK("; regenerate begin");
             if (!alive && !finished) {
                 // one LDS atomic per wave: the first fetching lane reserves a run of items for all fetching lanes; item =
                 // sample * 256 + slot, so simultaneous fetches are neighbouring pixels of one sample
@@ -315,6 +316,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                 }
             }
         }
+        RT_ASM_MARK("; regenerate end");
         if (__ballot(!finished) == 0) break;
         const int n_alive = __popcll(__ballot(alive));
         lap(0);
