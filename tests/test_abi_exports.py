@@ -29,3 +29,35 @@ def test_struct_layouts_match_header(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [C.sizeof(SceneDesc), C.sizeof(RenderParams), C.sizeof(RenderStats)]
+
+
+def test_scene_description_is_validated_before_any_gpu_call():
+    """rt_scene_create checks the whole description first (RT_EINVAL) and only then touches the device (RT_EHIP here: no GPU in this
+    container, and no CPU fallback either): malformed wrapper records of the round-3 object model are refused with a message, not
+    crashed on -- a chain that runs off the end of xform_data, box-boundary / rotatey / translate flags on primitives that cannot
+    carry them, unknown flag bits, indices out of range."""
+    import numpy as np
+    import oracle_lib as O
+    import raytracing_amd as R
+    R.load_library()
+    d = O.Scene.nested(60, 40, 3).export()
+
+    def error_of(desc):
+        with __import__("pytest").raises(R.RtError) as e:
+            R.Scene(desc)
+        return str(e.value)
+
+    import torch
+    if not torch.cuda.is_available():
+        assert "error -2" in error_of(d)                              # a well-formed scene gets as far as the device
+    cases = []
+    b = dict(d); b["xform_data"] = d["xform_data"].copy(); b["xform_data"][-1, 5] = 4 | 8; cases.append((b, "cannot continue"))
+    b = dict(d); b["xform_data"] = d["xform_data"].copy(); b["xform_data"][0, 5] = 8; cases.append((b, "ROTATEY and / or TRANSLATE"))
+    for flag, what in ((8, "RT_PRIM_VOLUME"), (2, "prim_xform"), (32, "unknown primitive flag")):
+        b = dict(d); b["prim_flags"] = d["prim_flags"].copy(); b["prim_flags"][2] |= flag; cases.append((b, what))     # primitive 2: a sphere
+    b = dict(d); b["prim_flags"] = d["prim_flags"].copy(); b["prim_flags"][8] |= 4; cases.append((b, "boundary BOX"))   # 8: a sphere-bounded volume
+    b = dict(d); b["prim_xform"] = d["prim_xform"].copy(); b["prim_xform"][2] = len(d["xform_data"]); cases.append((b, "prim_xform out of range"))
+    b = dict(d); b["node_child"] = d["node_child"].copy(); b["node_child"][3, 1] = 10 ** 6; cases.append((b, "child code out of range"))
+    for desc, what in cases:
+        msg = error_of(desc)
+        assert "error -1" in msg and what in msg, (what, msg)
