@@ -164,6 +164,19 @@ inline int32_t flattener::emit(const object* o)
     const int xi = chain_records();
     if (chain.size() != saved.size()) { chain = saved; chain_first = saved_first; }
     if (flip_parity) leaf.flags |= xi >= 0 ? RT_PRIM_FLAG_FLIP_OUTER : RT_PRIM_FLAG_FLIP;
+    // one object reached along two paths (both children of a span-1 node, or the same pointer added twice) is one primitive: fine as long
+    // as both paths wrap it alike -- a record has one set of flags and one transform chain
+    if (emitted.count(id)) {
+        const double* a = &out.xform_data[0];
+        bool same = out.prim_flags[id] == leaf.flags && (out.prim_xform[id] >= 0) == (xi >= 0);
+        for (int x0 = out.prim_xform[id], x1 = xi; same && x0 >= 0; x0++, x1++) {
+            for (int k = 0; k < RT_XFORM_STRIDE; k++) same &= a[(size_t) x0 * RT_XFORM_STRIDE + k] == a[(size_t) x1 * RT_XFORM_STRIDE + k];
+            if (!((int) a[(size_t) x0 * RT_XFORM_STRIDE + 5] & RT_XFORM_FLAG_CHAIN)) break;
+        }
+        if (!same) throw std::runtime_error("flatten: one object is used under two different sets of wrappers (give each use its own object)");
+        return ~id;
+    }
+    emitted.insert(id);
     store_prim(id, leaf);
     out.prim_xform[id] = xi;
     return ~id;

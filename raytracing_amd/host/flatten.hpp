@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <vector>
 
@@ -114,6 +115,7 @@ public:
     std::vector<flat_xform> chain;          // the wrappers around the object being emitted, outermost first
     int chain_first = -1;                   // first record of `chain` once written
     int flip_parity = 0;                    // the flips that count
+    std::set<int> emitted;                  // primitives whose record has been written
     void store_prim(int id, const flat_leaf& l)
     {
         out.prim_kind[id] = l.kind; out.prim_flags[id] = l.flags; out.prim_mat[id] = material_id(l.mat);

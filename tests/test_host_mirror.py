@@ -144,6 +144,24 @@ def test_nested_wrappers_groups_and_volume_boxes_flatten_like_the_oracle(golden_
     hs.free()
 
 
+def test_one_object_under_two_wrapper_sets_is_refused(tmp_path):
+    """The reference lets one object pointer appear twice, once moved (each use intersects it through its own wrappers); a flattened
+    primitive has one record, one set of flags and one transform chain, so the flattener refuses that scene instead of rendering one of the
+    two uses wrongly."""
+    import subprocess
+    src = tmp_path / "dup.cpp"
+    src.write_text('#include "rt_host.hpp"\n#include <cstdio>\nint main(){scene scn(32,24);sphere* s=new sphere(vec3d(0,1,0),1,new lambertian(vec3d(0.5,0.5,0.5)));'
+                   'scn.add_object(s);scn.add_object(new translate(s,vec3d(3,0,0)));scn.add_object(new sphere(vec3d(0,-100,0),100,new lambertian(vec3d(0.5,0.5,0.5))));'
+                   'scn.add_light(new flip(new planexz(-1,1,-1,1,5,new emissive(vec3d(4,4,4)))));scn.set_camera(camera(vec3d(0,2,8),vec3d(0,1,0),vec3d(0,1,0),40,32.0/24,0,1,0,1));'
+                   'scn.build_bvh();flat_scene f;try{scn.flatten(f);std::puts("flattened");}catch(const std::exception& e){std::printf("refused: %s\\n",e.what());}return 0;}\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dup"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "raytracing_amd", "host"), str(src), "-o", str(exe),
+                    "-L", os.path.join(root, "raytracing_amd"), "-lrtcore", "-lz", "-Wl,-rpath," + os.path.join(root, "raytracing_amd")], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    assert out.startswith("refused: flatten: one object is used under two different sets of wrappers"), out
+
+
 def test_png_roundtrip(tmp_path):
     """image_io.hpp: write a PNG with the host writer, read it back with the host reader through an image texture."""
     import subprocess
