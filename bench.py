@@ -353,7 +353,8 @@ def main():
         valu_frac = time_at_peak / secs
         # OBJ-loader scenes (triangles + phong only) walk the quantised four-wide nodes by default (rtcore.hip, RT_QNODES overrides)
         kernel_name = scene.kernel_name(mode)
-        quantised = fast and kernel_name.split(",")[2].strip() == "true"            # render_wave_kernel<R, count, wide nodes, scene class>
+        # render_wave_kernel<R, count, wide nodes, scene class>; render_wave_sorted_kernel<R, count, scene class> always walks the wide nodes
+        quantised = fast and ("render_wave_sorted_kernel" in kernel_name or kernel_name.split(",")[2].strip() == "true")
         # a fast-mode node record is 64 B and holds its children's boxes: four quantised ones or two fp32 ones
         node_bytes = 64.0 if fast else (56.0 if is_fp64 else 32.0)
         boxes_per_node = (4 if quantised else 2) if fast else 1

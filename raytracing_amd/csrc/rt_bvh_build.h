@@ -249,6 +249,60 @@ inline WideTree widen(const Tree& t, int budget)
     return w;
 }
 
+// Which visiting order pays on this tree (rt_wave.h node_step)?  The slots of a wide node are sorted along one axis and walked forwards or
+// backwards by the ray's sign on it -- no comparison of entry distances, 29 vector instructions fewer per visit.  On a surface mesh that
+// order is nearly the distance order (+1.8 % box tests on the 1.3 M-triangle mesh, -0.6 % time); in a sparse soup of small triangles it
+// is not (+27 % box tests, +9.6 % time on the 10 M-triangle soup).  This census walks `n_rays` bounced rays (origins on primitives chosen
+// at random, directions uniform on the sphere: a frame's rays start on surfaces, not in the empty parts of the scene's box) through
+// the tree under both orders, with real triangle tests so that the closest hit culls as it does in the kernel, and returns box tests
+// per ray: [0] slot order, [1] distance order.
+// `start(u in [0, 1), o)`: a point on the primitive that u picks; `hit(leaf_order_index, o, d, t_max, &t)`: the caller's primitive test.
+template <typename Start, typename Hit>
+inline void visit_order_census(const WideTree& wt, int n_rays, Start&& start, Hit&& hit, double out[2])
+{
+    out[0] = out[1] = 0;
+    if (wt.nodes.empty() || n_rays <= 0) return;
+    uint64_t s = 0x2545F4914F6CDD1Dull;
+    auto unit = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double) (s >> 11) * (1.0 / 9007199254740992.0); };
+    std::vector<int32_t> stack;
+    for (int r = 0; r < n_rays; r++) {
+        double o[3], d[3], inv[3];
+        start(unit(), o);
+        const double z = 2 * unit() - 1, phi = 6.283185307179586 * unit(), q = std::sqrt(std::max(0.0, 1 - z * z));
+        d[0] = q * std::cos(phi); d[1] = q * std::sin(phi); d[2] = z;
+        for (int k = 0; k < 3; k++) inv[k] = 1.0 / (std::fabs(d[k]) < 1e-30 ? 1e-30 : d[k]);
+        for (int policy = 0; policy < 2; policy++) {
+            double best = DBL_MAX;
+            stack.assign(1, 0);
+            while (!stack.empty()) {
+                const int32_t cur = stack.back(); stack.pop_back();
+                if (cur < 0) {
+                    const int code = ~cur, first = code >> 3, cnt = (code & 7) + 1;
+                    for (int k = 0; k < cnt; k++) { double t; if (hit(first + k, o, d, best, &t)) best = t; }
+                    continue;
+                }
+                const WideNode& n = wt.nodes[cur];
+                out[policy] += n.n;
+                double tn[4]; int ord[4], m = 0;
+                const bool rev = d[n.axis] < 0;
+                for (int i = 0; i < n.n; i++) {
+                    const int k = rev ? n.n - 1 - i : i;
+                    double t0 = 1e-3, t1 = best;
+                    for (int a = 0; a < 3; a++) {
+                        double lo = (n.box[k].lo[a] - o[a]) * inv[a], hi = (n.box[k].hi[a] - o[a]) * inv[a];
+                        if (lo > hi) std::swap(lo, hi);
+                        t0 = std::max(t0, lo); t1 = std::min(t1, hi);
+                    }
+                    if (t0 <= t1) { tn[k] = t0; ord[m++] = k; }
+                }
+                if (policy == 1) std::sort(ord, ord + m, [&](int a, int b) { return tn[a] < tn[b]; });
+                for (int i = m - 1; i >= 0; i--) stack.push_back(n.child[ord[i]]);      // the first to visit on top
+            }
+        }
+    }
+    out[0] /= n_rays; out[1] /= n_rays;
+}
+
 // One axis of a wide node (decoded in rt_wave.h slab_wide): lo[k] / hi[k] are the children's planes, already padded by the kernel's
 // fp32 decode error.  word = a float origin <= all lo whose low byte is the signed exponent e of the step 2^e (the kernel uses the
 // whole dword as the origin, so the origin must stay below the boxes whatever that byte holds); qlo / qhi: byte k = child k's low /

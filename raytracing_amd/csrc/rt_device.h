@@ -126,6 +126,8 @@ template <typename R> struct Scene {
     int32_t need_uv;                  // some material reads uv (image texture)
     const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
     const WNode* wnodes; int32_t wide_stack;   // the same tree collapsed to quantised four-wide nodes; stack entries a traversal of it can need
+    int32_t sorted_visit;             // wide nodes: visit the hit children by entry distance (a five-exchange network) instead of in slot order -- chosen per
+                                      // tree by rtcore.hip (rt_bvh_build.h visit_order_census): a sparse soup needs it, a surface mesh does not
     const Xform<R>* xforms;           // instance transforms (null: none)
     const uint32_t* ref_rank;         // by primitive id: index of the LAST entry of `ops` that names it, i.e. when the reference's walk visits it last.
                                       // Among surfaces at the same t (bit for bit) the reference ends up with the one it visits last (its range test

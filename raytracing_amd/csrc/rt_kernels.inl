@@ -46,6 +46,26 @@ hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const S
     return hipGetLastError();
 }
 
+// ... and its twin that visits the wide nodes' hit children by entry distance (Scene::sorted_visit)
+template <typename R, int kFull>
+hipError_t launch_wave_sorted(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters)
+{
+    if (lds > 48 * 1024) {
+        static LdsConfigured done;
+        std::atomic<size_t>* configured = done.of_current_device();
+        if (!configured) return hipErrorInvalidDevice;
+        if (lds > configured->load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_sorted_kernel<R, false, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_sorted_kernel<R, true, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+            configured->store(lds, std::memory_order_relaxed);
+        }
+    }
+    if (count) hipLaunchKernelGGL((render_wave_sorted_kernel<R, true, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
+    else hipLaunchKernelGGL((render_wave_sorted_kernel<R, false, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
+    return hipGetLastError();
+}
+
 // one variant of the decoupled kernel (rt_queue.h)
 template <typename R, bool kQuant, int kFull>
 hipError_t launch_queue(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, void* pools, unsigned int* locks)
@@ -106,9 +126,11 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
         if (a.kinds == 6) return launch_wave<RT_REAL, false, 6>(count, grid, lds, s, sc, a, accum, counters);          // ... with boxes or volumes
         if (a.kinds == 7) return launch_wave<RT_REAL, false, 7>(count, grid, lds, s, sc, a, accum, counters);          // ... with instances
         if (a.kinds == 3) {
+            if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 3>(count, grid, lds, s, sc, a, accum, counters);
             if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
             return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);
         }
+        if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 0>(count, grid, lds, s, sc, a, accum, counters);
         if (a.quantised) return launch_wave<RT_REAL, true, 0>(count, grid, lds, s, sc, a, accum, counters);
         return launch_wave<RT_REAL, false, 0>(count, grid, lds, s, sc, a, accum, counters);
     }

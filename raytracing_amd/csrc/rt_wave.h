@@ -146,7 +146,7 @@ template <typename R> __device__ inline void slab_wide(const WNode& n, const Tra
 
 // One node visit of one lane: test the children's boxes, go on with the nearest one hit and push the others (farthest first), or
 // pop.  kQuant: four-wide quantised nodes (WNode), else the binary fp32 nodes (BNode).  stack_at(address) names an LDS stack entry.
-template <typename R, bool kQuant, bool kCount, typename StackAt>
+template <typename R, bool kQuant, bool kCount, bool kSorted = false, typename StackAt>
 __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, StackAt&& stack_at, VisitStats& vs)
 {
     if constexpr (kQuant) {
@@ -157,7 +157,11 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         // five-exchange sort this replaces was 29 of the visit's 122 vector instructions, for 1..3 % fewer visits
         // (tools/trav_policy_sim.cpp).  The reversal is folded into the byte selectors of the plane words, so the hit flags come out
         // of the box tests in visiting order; the four child codes take a select each.
-#ifdef RT_SORTED_VISIT      // A/B only (make EXTRA=-DRT_SORTED_VISIT): round 2's visit -- hit children sorted by entry distance with a five-exchange network
+        // ... unless the tree says otherwise (Scene::sorted_visit): in a sparse soup of small triangles slot order is far from distance order
+        // (+27 % box tests on the 10 M-triangle soup), and there the hit children are sorted by entry distance with a five-exchange
+        // network, as in round 2.  A kernel of its own (render_wave_sorted_kernel): as a wave-uniform branch in one kernel the second
+        // path cost the first 12 % (mesh 4K fp64 42.7 -> 47.9 ms per 32 spp)
+        if constexpr (kSorted) {
         float t4[4]; bool h4[4];
         slab_wide<R>(n, tv, 0u, t_min, h4, t4);
         if (kCount && first_active_lane()) vs.w_node++;
@@ -177,7 +181,8 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
         if (t4[0] < __builtin_inff()) tv.cur = c4[0];
         else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
-#else
+        }
+        else {
         const uint32_t flip = __builtin_amdgcn_perm(tv.sg, tv.sg, n.n);
         bool h[4];
         slab_wide<R>(n, tv, flip, t_min, h);
@@ -191,7 +196,7 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         if (h[1] && h[0]) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c1; }
         if (h[0] || h[1] || h[2] || h[3]) tv.cur = h[0] ? c0 : h[1] ? c1 : h[2] ? c2 : c3;
         else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
-#endif
+        }
         RT_ASM_MARK("; wide node_step end");
     }
     else {
@@ -214,9 +219,12 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
     }
 }
 
-template <typename R, bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32)) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum,
-                                                                         unsigned long long* __restrict__ counters)
+// waves per SIMD a variant is compiled for
+template <typename R, int kFull> constexpr int wave_kernel_waves()
+{ return sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32; }
+
+template <typename R, bool kCount, bool kQuant, int kFull, bool kSorted>
+__device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const RenderArgs& a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut
     // into super-tiles of 8 x 8 tiles, dealt to the XCDs round-robin (neighbouring super-tiles cost about the same, so the XCDs
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
                     const unsigned c2 = (unsigned) __popcll(__ballot(!alive));
                     census[0] += c0; census[1] += c1; census[2] += c2;
                 }
-                if (tv.cur >= 0) node_step<R, kQuant, kCount>(sc, tv, t_min, stack_at, vs);
+                if (tv.cur >= 0) node_step<R, kQuant, kCount, kSorted>(sc, tv, t_min, stack_at, vs);
             }
             lap(1);
             // leaves
@@ -529,6 +537,18 @@ __global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_
     }
 }
 
+template <typename R, bool kCount, bool kQuant, int kFull>
+__global__ void __launch_bounds__(256, (wave_kernel_waves<R, kFull>())) render_wave_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    render_wave_body<R, kCount, kQuant, kFull, false>(sc, a, accum, counters);
+}
+// the same kernel over wide nodes whose hit children are visited by entry distance (Scene::sorted_visit: sparse soups)
+template <typename R, bool kCount, int kFull>
+__global__ void __launch_bounds__(256, (wave_kernel_waves<R, kFull>())) render_wave_sorted_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    render_wave_body<R, kCount, true, kFull, true>(sc, a, accum, counters);
+}
+
 // Closest hit of explicit rays through the fast tree, with the render kernel's own culling code (trav_begin, node_step: slab_fma / slab_wide,
 // LDS stack) and primitive tests: test hook behind rt_first_hit_tree.  R = double must return the reference walk's primitive, t bits
 // and frontward flag (the closest hit does not depend on the tree), which is what pins RT_MODE_FAST_FP64's traversal.
@@ -553,7 +573,10 @@ __global__ void __launch_bounds__(256) first_hit_tree_kernel(Scene<R> sc, const 
     VisitStats unused;
     trav_begin(tv, best, r, stack_base);
     while (tv.cur != RT_BVH_SENTINEL) {
-        if (tv.cur >= 0) node_step<R, kQuant, false>(sc, tv, t_min, stack_at, unused);
+        if (tv.cur >= 0) {
+            if (kQuant && sc.sorted_visit) node_step<R, kQuant, false, kQuant>(sc, tv, t_min, stack_at, unused);      // the visiting order the scene's renders use
+            else node_step<R, kQuant, false, false>(sc, tv, t_min, stack_at, unused);
+        }
         else {
             const int code = ~tv.cur, first = code >> 3, count = (code & 7) + 1;
             for (int k = 0; k < count; k++) {

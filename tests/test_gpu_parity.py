@@ -491,6 +491,34 @@ def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     osc.free()
 
 
+@pytest.mark.parametrize("name", ["obj", "ngon"])
+def test_both_visiting_orders_of_the_wide_nodes_find_the_same_hits(R, golden_dir, monkeypatch, name):
+    """The wide nodes are visited in slot order (children stored sorted along one axis; the default for surface meshes) or with the hit
+    children sorted by entry distance (chosen per tree by rtcore.hip's census for sparse soups; RT_SORTED_VISIT forces either): the order
+    decides how much is culled, never what is found.  First hits through rt_first_hit_tree in fp64 -- primitive, t bits, frontward --
+    and the fp64 frame on the same streams must be identical under both."""
+    g, m = load(golden_dir, name)
+    rays = g["obj_fh_rays"].reshape(-1, 7)
+    w, h = m["width"], m["height"]
+    out = []
+    for order in ("0", "1"):
+        monkeypatch.setenv("RT_QNODES", "1")
+        monkeypatch.setenv("RT_SORTED_VISIT", order)
+        osc = SCENES[name][1](golden_dir, m)
+        sc = R.Scene(osc.export())
+        fh = sc.first_hit_tree(rays, fp64=True)
+        img, _, st = sc.render_to_host(w, h, 0, 8, 12, R.MODE_FAST_FP64, seed=5, flags=R.FLAG_COUNT_TESTS)
+        out.append((fh, img, st))
+        sc.destroy()
+        osc.free()
+    (fa, ia, sa), (fb, ib, sb) = out
+    assert np.array_equal(fa["prim"], fb["prim"]) and np.array_equal(fa["t"].view(np.uint64), fb["t"].view(np.uint64)) and np.array_equal(fa["front"], fb["front"])
+    assert sa["rays"] == sb["rays"] and sa["rejected"] == sb["rejected"]
+    assert float(np.abs(ia - ib).max()) <= 1e-13 * float(np.abs(ia).max())
+    if name == "obj":
+        assert sa["box_tests"] != sb["box_tests"], "the two orders are two different walks"       # (the n-gon scene's tree is too small to show it)
+
+
 def test_depth_limited_tree_same_frame(R, golden_dir, monkeypatch):
     """RT_BVH_DEPTH: the fast tree's depth limit (default 26, so that the traversal stack lets five workgroups share a CU's LDS;
     a split whose larger side could not be finished within the limit is replaced by a median split).  The closest hit does not
