@@ -105,7 +105,7 @@ struct alignas(16) WNode {
 
 // per-primitive side record, by primitive id.  Triangles: vertex normals and uvs (cold: read once per hit).  Boxes: n[0..2] is the
 // translate target (read by the box test).
-template <typename R> struct TriShade { R n[9]; R uv[6]; R pad; };
+template <typename R> struct TriShade { R n[9]; R uv[6]; R area; };      // area: light_tris only -- length(cross(e1, e2)) / 2 (polygon.hpp:146), a constant of the scene, set by rt_scene_create
 template <typename R> struct Mat { int32_t kind, tex; R d[16]; };
 template <typename R> struct Tex { int32_t kind, a, b, ch, color_based; uint32_t offset; R rgb[3]; R pad; };
 // what a primitive test may need besides the hot record: side records by primitive id, instance transforms
@@ -1041,29 +1041,39 @@ template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, c
 }
 #endif
 
-template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo, bool fixed = false)
+// normalize(a) for a caller that already holds length(a): the same operations (vec3.hpp: zero stays zero, else (1 / l) * a)
+template <typename R> __device__ inline vec3<R> normalize_by(const vec3<R>& a, R l) { return l == R(0) ? vec3<R>() : a / l; }
+template <> __device__ inline vec3<float> normalize_by<float>(const vec3<float>& a, float) { return normalize(a); }       // fp32: one v_rsq_f32
+
+// wo_len = length(wo.d): the light pdf of the same direction needs it too (light_pdf), so the shade pass takes the root once
+template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo, R wo_len, bool fixed = false)
 {
     switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN: {                                                               // material.hpp:37-41
-        R c = dot(h.normal, normalize(wo.d));
+        R c = dot(h.normal, normalize_by(wo.d, wo_len));
         return c > R(0) ? c / consts<R>::pi : R(0);
     }
     case RT_MAT_METAL: {                                                                    // material.hpp:84-88
-        R c = dot(h.normal, normalize(wo.d));
+        R c = dot(h.normal, normalize_by(wo.d, wo_len));
         return c > consts<R>::eps ? R(1) : R(0);
     }
     case RT_MAT_PHONG: if constexpr (kMat == 2 || kMat == 3) return R(0); else {             // material.hpp:257-266
-        R c = dot(h.normal, normalize(wo.d));
+        R c = dot(h.normal, normalize_by(wo.d, wo_len));
         if (!fixed && nz3(m.d + 4) && uniform<R>(g) < R(0.5)) return c > consts<R>::eps ? R(1) : R(0);   // fixed: the diffuse lobe's pdf, no second roll
         return c > R(0) ? c / consts<R>::pi : R(0);
     }
     default: return R(0);                                                                   // material.hpp:14
     }
 }
+template <typename R, int kMat = 0> __device__ inline R mat_pdf(Rng& g, const Mat<R>& m, const Hit<R>& h, const Ray<R>& wo, bool fixed = false)
+{
+    return mat_pdf<R, kMat>(g, m, h, wo, length(wo.d), fixed);
+}
 
 // ------------------------------------------------------------------ lights (group.hpp:104-119 over planexz / triangle)
 // kLight = 1: every light of the scene is a rect (no triangle lights)
-template <typename R, int kLight = 0> __device__ inline R light_pdf(const Scene<R>& sc, int li, const vec3<R>& origin, const vec3<R>& value)
+// len = length(value), taken once by the caller for all lights
+template <typename R, int kLight = 0> __device__ inline R light_pdf(const Scene<R>& sc, int li, const vec3<R>& origin, const vec3<R>& value, R len)
 {
     const Prim<R>& p = sc.lights[li];
     Ray<R> r; r.o = origin; r.d = value; r.time = R(0);                                     // ray(origin, value): time 0, t_min 1e-3, t_max inf
@@ -1084,11 +1094,9 @@ template <typename R, int kLight = 0> __device__ inline R light_pdf(const Scene<
         vec3<R> n0(s.n[0], s.n[1], s.n[2]), n1(s.n[3], s.n[4], s.n[5]), n2(s.n[6], s.n[7], s.n[8]);
         vec3<R> n = (u * n1 + v * n2) + w * n0;
         normal = dot(r.d, n) < R(0) ? n : -n;
-        vec3<R> e1(p.g[3], p.g[4], p.g[5]), e2(p.g[6], p.g[7], p.g[8]);
-        area = length(cross(e1, e2)) / R(2);
+        area = s.area;                                                                      // length(cross(e1, e2)) / 2, polygon.hpp:146
     }
     else return R(0);                                                                       // object.hpp:16
-    R len = length(value);
     R dist2 = t * t * len * len;
     R cosine = rt_abs(dot(value, normal) / len);
     return dist2 / (cosine * area);
@@ -1113,12 +1121,16 @@ template <typename R, int kLight = 0> __device__ inline vec3<R> light_rand(const
     return vec3<R>(R(1), R(0), R(0));                                                       // object.hpp:17
 }
 
-template <typename R, int kLight = 0> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value)
+template <typename R, int kLight = 0> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value, R len)
 {
     R weight = R(1) / R(sc.n_lights);
     R avg = R(0);
-    for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf<R, kLight>(sc, i, origin, value);
+    for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf<R, kLight>(sc, i, origin, value, len);
     return avg;
+}
+template <typename R, int kLight = 0> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value)
+{
+    return lights_pdf<R, kLight>(sc, origin, value, length(value));
 }
 
 // ------------------------------------------------------------------ camera (camera.hpp:62-68)

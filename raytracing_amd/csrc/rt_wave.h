@@ -418,8 +418,9 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                         }
                         else {                                                              // raytracing.cpp:55-61
                             if (uniform<R>(g) < R(0.5)) { wo.o = h.pos; wo.from = h.id; wo.d = light_rand<R, class_light(kFull)>(sc, g, h.pos); wo.time = ray.time; }
-                            mpdf = mat_pdf<R, class_mat(kFull)>(g, m, h, wo, fixed);
-                            pdf = R(0.5) * (lights_pdf<R, class_light(kFull)>(sc, h.pos, wo.d) + mpdf);
+                            const R wo_len = length(wo.d);                                  // one root for the material's pdf and the lights'
+                            mpdf = mat_pdf<R, class_mat(kFull)>(g, m, h, wo, wo_len, fixed);
+                            pdf = R(0.5) * (lights_pdf<R, class_light(kFull)>(sc, h.pos, wo.d, wo_len) + mpdf);
                         }
                         // RT_FLAG_COMPAT_FIXED: a direction of zero probability contributes nothing (the reference forms 0 * inf)
                         if (fixed && (!(pdf > R(0)) || !(mpdf > R(0)))) dropped = true;

@@ -524,6 +524,14 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     for (int i = 0; i < d->n_lights; i++)
         fill_prim<R>(lights[i], light_tri ? &ltris[i] : nullptr, d->light_kind[i], d->light_flags[i], d->light_mat ? d->light_mat[i] : 0,
                      d->light_data + (size_t) i * RT_PRIM_STRIDE, i);
+    // triangle::pdf's area (polygon.hpp:146) is a constant of the light: taken here, once, with the expressions the kernels used to
+    // evaluate per shaded hit (products and sums unfused, IEEE root and division: the same bits)
+    for (int i = 0; light_tri && i < d->n_lights; i++) {
+#pragma clang fp contract(off)
+        if (lights[i].kind() != RT_PRIM_TRIANGLE) continue;
+        const rt::Prim<R>& p = lights[i];
+        ltris[i].area = rt::length(rt::cross(rt::vec3<R>(p.g[3], p.g[4], p.g[5]), rt::vec3<R>(p.g[6], p.g[7], p.g[8]))) / R(2);
+    }
 
     std::vector<rt::Mat<R>> mats(d->n_mats);
     for (int i = 0; i < d->n_mats; i++) {
