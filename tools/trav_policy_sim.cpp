@@ -99,6 +99,8 @@ static int widen_rec(const rtb::Tree& t, int32_t bin, int W, WT& out)
 }
 
 struct Counts { double visits = 0, box = 0, leaf = 0, pushes = 0, entries = 0; int max_stack = 0; long rays = 0; long hits = 0; };
+static std::vector<int> g_level;            // level of each wide node (root 0); set: traverse() adds its visits to g_level_visits
+static std::vector<double> g_level_visits;
 
 enum Policy { SORT_ALL, AXIS_ORDER, AXIS_LEAVES_FIRST, NEAREST_THEN_AXIS };
 
@@ -122,6 +124,7 @@ static double traverse(const WT& wt, const std::vector<Tri>& tris, const std::ve
         if (cur < 0) { leaf(cur); continue; }
         const WN& n = wt.nodes[cur];
         c.visits++;
+        if (!g_level.empty()) g_level_visits[g_level[cur]]++;
         const int nc = (int) n.child.size();
         c.box += nc;
         double tn[8]; bool h[8]; int nh = 0;
@@ -194,6 +197,12 @@ int main(int argc, char** argv)
         size_t slots = 0; for (auto& n : wt.nodes) slots += n.child.size();
         std::printf("== %d-wide: %zu nodes, %.2f children per node\n", W, wt.nodes.size(), (double) slots / wt.nodes.size());
         const char* names[] = { "sort all by distance (today)", "axis order, forwards/backwards by ray sign", "axis order, hit leaves first", "nearest by distance, rest in axis order" };
+        // visits by tree level (4-wide, slot order): how much of the walk the top of the tree takes -- what a copy of the top levels in
+        // LDS could serve
+        g_level.assign(wt.nodes.size(), 0);
+        std::vector<size_t> per_level(64, 0);
+        for (size_t i = 0; i < wt.nodes.size(); i++) { per_level[g_level[i]]++; for (int32_t ch : wt.nodes[i].child) if (ch >= 0) g_level[ch] = g_level[i] + 1; }   // parents precede children
+        g_level_visits.assign(64, 0.0);
         for (int gen = 0; gen < 3; gen++) {
             if (W == 4 && gen < 2) rays[gen + 1].clear();
             for (int pol = 0; pol < 4; pol++) {
@@ -214,6 +223,10 @@ int main(int argc, char** argv)
                             gen, names[pol], c.rays, 100.0 * c.hits / std::max(1l, c.rays), c.visits / c.rays, c.box / c.rays, c.leaf / c.rays, c.pushes / c.rays, c.entries / c.rays, c.max_stack);
             }
         }
+        double all = 0, cum = 0; size_t nodes = 0;
+        for (double x : g_level_visits) all += x;
+        for (int l = 0; l < 64 && per_level[l]; l++) { cum += g_level_visits[l]; nodes += per_level[l]; std::printf("  level %2d: %8zu nodes (%9zu so far, %8.1f KB)  visits %5.1f %%  cumulative %5.1f %%\n", l, per_level[l], nodes, nodes * 64 / 1024.0, 100 * g_level_visits[l] / all, 100 * cum / all); }
+        g_level.clear();
     }
     return 0;
 }
