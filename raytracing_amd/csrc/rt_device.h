@@ -468,7 +468,7 @@ constexpr bool class_no_tri(int kFull) { return kFull == 5 || kFull == 6 || kFul
 constexpr bool class_boxes(int kFull) { return kFull == 1 || kFull == 2 || kFull == 6 || kFull == 7; }      // boxes and volumes
 constexpr bool class_instances(int kFull) { return kFull == 2 || kFull == 7; }
 constexpr int class_mat(int kFull) { return class_is_obj(kFull) ? 1 : (kFull == 5 ? 2 : (class_no_tri(kFull) ? 3 : 0)); }   // kMat of the mat_* functions
-constexpr int class_tex(int kFull) { return class_no_tri(kFull) ? 2 : 0; }                                                 // kTex of tex_color
+constexpr int class_tex(int kFull) { return class_no_tri(kFull) ? 2 : (class_is_obj(kFull) ? 1 : 0); }                                                 // kTex of tex_color
 constexpr int class_light(int kFull) { return class_no_tri(kFull) ? 1 : 0; }                                               // kLight of the light functions
 
 template <typename R, int kFull = 2> __device__ inline bool prim_t_local(const Prim<R>& p, Side<R> aux, const Ray<R>& r, R t_min, R t_max, R& t, Rng* g)
@@ -835,7 +835,43 @@ __device__ inline int closest_hit_bvh(const BNode* __restrict__ nodes, const Pri
 }
 
 // ------------------------------------------------------------------ textures and materials
-template <typename R> __device__ inline R checker_sine(const vec3<R>& pos) { return rt_sin(R(10) * pos.x) * rt_sin(R(10) * pos.y) * rt_sin(R(10) * pos.z); }   // texture.hpp:67
+// checker::value (texture.hpp:65-74) takes `odd` where sin(10 x) sin(10 y) sin(10 z) < 0: only the SIGN of the product is used.
+// fp64: three library sines were ~400 of a shade pass's vector instructions on every scene with the checkered ground.  The sign of sin(t)
+// is the parity of floor(t / pi): k = rint(|t| / pi), then the sign of r = |t| - k pi decides between the intervals k - 1 and k.  r is
+// taken against pi = P1 + P2 (106 bits): k P1 = p + e exactly (fma), |t| - p is exact where it matters (Sterbenz: near a multiple of pi),
+// and what is left out (k times the bits of pi below P2, the roundings of k P2 and of the last sum: < 1e-23 for |t| < 2^30) is far below the
+// 4.7e-19 no double comes closer to a multiple of pi / 2 than (the bound behind fdlibm's argument reduction) -- so the computed sign IS
+// the sign of the true sine, which is what any libm's sin(t) carries (its error is < 1 ulp of a value that is never that close to 0).
+// Zero (t = +-0: sin = +-0, product not < 0), NaN / infinity (sin = NaN, `NaN < 0` false) and |t| >= 2^30 go the library's way.
+// sign of sin(t) for 0 < |t| < 2^30, branch-free: true where sin(t) < 0
+__device__ inline bool sine_negative(double t)
+{
+    const double P1 = 0x1.921fb54442d18p+1, P2 = 0x1.1a62633145c07p-53, INV_PI = 0x1.45f306dc9c883p-2;
+    const double a = fabs(t);
+    const double k = __builtin_rint(a * INV_PI);
+    const double p = k * P1, e = __builtin_fma(k, P1, -p);
+    const double r = __builtin_fma(-k, P2, (a - p) - e);
+    const bool odd = ((int) k & 1) != 0;
+    return (r >= 0.0 ? odd : !odd) != (t < 0.0);
+}
+__device__ inline int sine_sign(double t)                     // -1 / 0 / +1: sin(t) negative / zero / positive; 2: not a number (test hook, libm_kernel)
+{
+    if (!(fabs(t) < 1073741824.0)) { const double s = rt_sin(t); return s < 0.0 ? -1 : s > 0.0 ? 1 : s == 0.0 ? 0 : 2; }
+    return t == 0.0 ? 0 : sine_negative(t) ? -1 : 1;
+}
+// the cold side of checker_odd, out of line: inlined under its branch, three copies of the library's sine cost every kernel variant
+// scalar-register spills around the block (one copy in a loop: vector spills instead)
+__device__ __attribute__((noinline)) inline bool checker_odd_library(double tx, double ty, double tz) { return rt_sin(tx) * rt_sin(ty) * rt_sin(tz) < 0.0; }
+template <typename R> __device__ inline bool checker_odd(const vec3<R>& pos)
+{
+    const R tx = R(10) * pos.x, ty = R(10) * pos.y, tz = R(10) * pos.z;                                           // texture.hpp:67
+    // one branch for all three: the library's sines where an argument is huge or not a number (never, in a scene of ordinary size)
+    if (!(rt_abs(tx) < R(1073741824.0) && rt_abs(ty) < R(1073741824.0) && rt_abs(tz) < R(1073741824.0)))          // (a NaN compares false)
+        return checker_odd_library(tx, ty, tz);
+    const bool zero = tx == R(0) || ty == R(0) || tz == R(0);                                                     // a factor +-0: the product is not < 0
+    return !zero && (sine_negative(tx) != sine_negative(ty)) != sine_negative(tz);
+}
+template <typename R> __device__ inline R checker_sine(const vec3<R>& pos) { return rt_sin(R(10) * pos.x) * rt_sin(R(10) * pos.y) * rt_sin(R(10) * pos.z); }
 // fp32: only the sign is used.  The hardware sine takes revolutions and is exact enough after taking the fraction
 // (v_fract_f32 + v_sin_f32 instead of three range-reduced sinf calls, ~300 instructions).
 template <> __device__ inline float checker_sine<float>(const vec3<float>& pos)
@@ -844,30 +880,37 @@ template <> __device__ inline float checker_sine<float>(const vec3<float>& pos)
     auto s = [](float rev) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev)); };
     return s(k * pos.x) * s(k * pos.y) * s(k * pos.z);
 }
-// kTex = 2: the scene holds no image texture
+template <> __device__ inline bool checker_odd<float>(const vec3<float>& pos) { return checker_sine<float>(pos) < 0.0f; }
+// image_texture::value (texture.hpp:95-124)
+template <typename R> __device__ inline vec3<R> tex_image(const uint8_t* __restrict__ pixels, const Tex<R>& t, R u, R v)
+{
+    if (t.a <= 0) return vec3<R>(R(0), R(1), R(1));
+    R uu = u < R(0) ? R(0) : (u > R(1) ? R(1) : u);
+    R vv = R(1) - (v < R(0) ? R(0) : (v > R(1) ? R(1) : v));
+    int x = (int) (uu * t.a), y = (int) (vv * t.b);
+    if (x >= t.a) x = t.a - 1;
+    if (y >= t.b) y = t.b - 1;
+    const uint8_t* b = pixels + t.offset + ((size_t) y * t.a * t.ch + (size_t) x * t.ch);
+    const R scale = R(1) / R(255);
+    vec3<R> c = scale * vec3<R>(R(b[0]), R(b[1]), R(b[2]));
+    if (t.color_based) return vec3<R>(rt_pow(c.x, R(2.2)), rt_pow(c.y, R(2.2)), rt_pow(c.z, R(2.2)));
+    return c;
+}
+// ... out of line for the general scene classes: the texel address arithmetic and three pow() calls are bulk most of their shade passes
+// never run, and inlined they sit in the register allocation of every one (see checker_odd_library).  The OBJ-loader class keeps it
+// inline (kTex = 1 below: measured both ways)
+template <typename R> __device__ __attribute__((noinline)) vec3<R> tex_image_call(const uint8_t* __restrict__ pixels, const Tex<R>& t, R u, R v) { return tex_image<R>(pixels, t, u, v); }
+// kTex = 2: the scene holds no image texture; 1: it holds no checker (OBJ-loader scenes: rtcore.hip scene_kinds)
 template <typename R, int kTex = 0> __device__ inline vec3<R> tex_color(const Scene<R>& sc, int ti, const vec3<R>& pos, R u, R v)
 {
     for (int level = 0; level < 8; level++) {
         const Tex<R>& t = sc.texs[ti];
         if (t.kind == RT_TEX_CONSTANT) return vec3<R>(t.rgb[0], t.rgb[1], t.rgb[2]);        // texture.hpp:32-35
-        if (t.kind == RT_TEX_CHECKER) {                                                     // texture.hpp:65-74
-            R sine = checker_sine(pos);
-            ti = sine < R(0) ? t.a : t.b;
+        if (kTex != 1 && t.kind == RT_TEX_CHECKER) {                                         // texture.hpp:65-74
+            ti = checker_odd(pos) ? t.a : t.b;
             continue;
         }
-        if (kTex != 2 && t.kind == RT_TEX_IMAGE) {                                          // texture.hpp:95-124
-            if (t.a <= 0) return vec3<R>(R(0), R(1), R(1));
-            R uu = u < R(0) ? R(0) : (u > R(1) ? R(1) : u);
-            R vv = R(1) - (v < R(0) ? R(0) : (v > R(1) ? R(1) : v));
-            int x = (int) (uu * t.a), y = (int) (vv * t.b);
-            if (x >= t.a) x = t.a - 1;
-            if (y >= t.b) y = t.b - 1;
-            const uint8_t* b = sc.pixels + t.offset + ((size_t) y * t.a * t.ch + (size_t) x * t.ch);
-            const R scale = R(1) / R(255);
-            vec3<R> c = scale * vec3<R>(R(b[0]), R(b[1]), R(b[2]));
-            if (t.color_based) return vec3<R>(rt_pow(c.x, R(2.2)), rt_pow(c.y, R(2.2)), rt_pow(c.z, R(2.2)));
-            return c;
-        }
+        if (kTex != 2 && t.kind == RT_TEX_IMAGE) return kTex == 1 ? tex_image<R>(sc.pixels, t, u, v) : tex_image_call<R>(sc.pixels, t, u, v);
         break;
     }
     return vec3<R>();
@@ -1456,7 +1499,7 @@ __global__ void path_kernel(Scene<R> sc, RenderArgs a, int i, int j, int k, doub
 }
 
 // the device library's results for the libm calls of a path (operations as oracle/rt_oracle.c numbers them: 1 sin, 2 cos, 3 acos,
-// 4 atan2(x, y), 5 pow(x, y), 6 log), through the same rt_* overloads the kernels call
+// 4 atan2(x, y), 5 pow(x, y), 6 log), through the same rt_* overloads the kernels call; 7: sine_sign(x), the checker texture's sign of sin(x)
 __global__ void libm_kernel(const int32_t* __restrict__ op, const double* __restrict__ x, const double* __restrict__ y, int n, double* __restrict__ out)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1469,6 +1512,7 @@ __global__ void libm_kernel(const int32_t* __restrict__ op, const double* __rest
     case 4: r = rt_atan2(x[idx], y[idx]); break;
     case 5: r = rt_pow(x[idx], y[idx]); break;
     case 6: r = rt_log(x[idx]); break;
+    case 7: r = (double) sine_sign(x[idx]); break;
     default: break;
     }
     out[idx] = r;

@@ -106,7 +106,7 @@ struct rt_scene {
     bool has_volume = false;                  // RT_PRIM_VOLUME present: needs the path's random stream during traversal
     bool has_box = false;                     // RT_PRIM_BOX present
     bool only_spheres = true;                 // no triangle, no phong, no image texture, rect lights only (fog only with volumes): the lean variants 5 / 6 / 7
-    bool only_triangles = true;               // every primitive is an RT_PRIM_TRIANGLE and every material an RT_MAT_PHONG (an OBJ-loader scene)
+    bool only_triangles = true;               // every primitive is an RT_PRIM_TRIANGLE, every material an RT_MAT_PHONG, no checker texture (an OBJ-loader scene)
     unsigned long long* counters = nullptr;   // [0] rays, [1] rejected samples, [2] box tests, [3] leaf tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool pending = false;                     // an rt_render without stats has been launched and not yet waited for
@@ -684,6 +684,7 @@ int rt_scene_create(const rt_scene_desc* desc, rt_scene** scene_out)
     s->n_lights = desc->n_lights; s->n_prims = desc->n_prims; s->n_ops = (int32_t) f.op_prim.size();
     for (int i = 0; i < desc->n_prims; i++) { s->has_volume |= desc->prim_kind[i] == RT_PRIM_VOLUME; s->has_box |= desc->prim_kind[i] == RT_PRIM_BOX; s->only_triangles &= desc->prim_kind[i] == RT_PRIM_TRIANGLE; }
     for (int i = 0; i < desc->n_mats; i++) s->only_triangles &= desc->mat_kind[i] == RT_MAT_PHONG;
+    for (int i = 0; i < desc->n_tex; i++) s->only_triangles &= desc->tex_kind[i] != RT_TEX_CHECKER;      // (the OBJ loader makes none; a description that has one takes the general variant)
     auto is_rect = [](int k) { return k == RT_PRIM_PLANEXY || k == RT_PRIM_PLANEYZ || k == RT_PRIM_PLANEXZ; };
     for (int i = 0; i < desc->n_prims; i++) s->only_spheres &= desc->prim_kind[i] != RT_PRIM_TRIANGLE;
     for (int i = 0; i < desc->n_lights; i++) s->only_spheres &= is_rect(desc->light_kind[i]);

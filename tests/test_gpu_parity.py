@@ -568,6 +568,38 @@ def test_converged_image_matches_cpu_reference_independent_streams(R, golden_dir
     osc.free()
 
 
+def test_checker_sign_is_the_sign_of_the_library_sine(R):
+    """The fp64 kernels take the checker texture's choice (texture.hpp:67-68: sin(10x) sin(10y) sin(10z) < 0) from the parity of
+    floor(t / pi) instead of three library sines (rt_device.h sine_sign).  Held here, through rt_debug_libm op 7, to the sign of the host
+    libm's sin on random arguments of every magnitude, on the doubles next to 200 000 multiples of pi (where one wrong bit of the reduction
+    would show), next to half-multiples (where k = rint(t / pi) may round either way), on zeros, infinities, NaN and arguments beyond the
+    2^30 where the function hands over to the library."""
+    import math
+    rng = np.random.default_rng(5)
+    xs = [rng.uniform(-1, 1, 400000) * np.exp2(rng.integers(-40, 31, 400000))]
+    k = np.concatenate([np.arange(1, 100001), rng.integers(100001, 341782637, 100000)]).astype(np.longdouble)
+    pi = np.longdouble("3.14159265358979323846264338327950288")
+    if np.finfo(np.longdouble).nmant >= 63:              # x86-64: 64-bit mantissa, enough to land on the neighbouring doubles
+        c = (k * pi).astype(np.float64)
+        hlf = ((k + np.longdouble(0.5)) * pi).astype(np.float64)
+        for d in (0, 1, 2):
+            up, dn = c.copy(), c.copy()
+            for _ in range(d):
+                up, dn = np.nextafter(up, np.inf), np.nextafter(dn, -np.inf)
+            xs += [up, dn, -up, -dn]
+        xs += [hlf, np.nextafter(hlf, np.inf), np.nextafter(hlf, -np.inf)]
+    xs.append(np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** 30, -(2.0 ** 30), np.nextafter(2.0 ** 30, 0), 1e300, -1e300, 5e-324, -5e-324, math.pi, -math.pi]))
+    x = np.concatenate(xs)
+    got = R.debug_libm(np.full(len(x), 7), x, np.zeros(len(x)))
+    with np.errstate(invalid="ignore"):
+        s = np.array([math.sin(v) if math.isfinite(v) else math.nan for v in x[-14:]])
+        want_tail = np.where(np.isnan(s), 2, np.sign(s))
+        sn = np.sin(x[:-14])                              # numpy's own sine: the sign is all that is read
+    want = np.concatenate([np.sign(sn), want_tail])
+    bad = np.flatnonzero(got != want)
+    assert len(bad) == 0, [(float(x[i]).hex(), float(got[i]), float(want[i])) for i in bad[:8]]
+
+
 def test_empty_work_is_well_defined(R, golden_dir):
     """Edge cases of the sample / row / depth ranges in every kernel variant: an empty sample range, an empty row range and
     max_depth 0 (trace() returns black at once, raytracing.cpp:32) leave zeros (or, with RT_FLAG_ACCUMULATE, the buffer
