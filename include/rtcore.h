@@ -281,7 +281,7 @@ int rt_checkpoint_load(const char* path, void* accum_dev, int accum_is_fp64, int
 /* Test tooling for the fp64-vs-CPU comparison (tools/first_divergence.py; no counterpart in the reference).  rt_debug_path: the path of ONE
  * stream (pixel row i, column j, global sample k) through the reference-order walk with the render kernel's own functions -- per segment a row
  * of 9 doubles: ray origin, direction, time, hit distance (0: miss), primitive id (-1); *n_out = segments traced (rows beyond `cap` are not
- * stored).  rt_debug_libm: the device library's results for n calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log; 7: the sign of sin(x) as the checker texture takes it -- -1, 0, +1, or 2 for not-a-number), so that a
+ * stored).  rt_debug_libm: the device library's results for n calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log; 7: the sign of sin(x) as the checker texture takes it -- -1, 0, +1, or 2 for not-a-number; 8: x^5 as the dielectric's reflectance takes it), so that a
  * CPU path's libm calls can be replayed on the GPU and compared bit for bit.  Both synchronous, both allocate. */
 int rt_debug_path(rt_scene* scene, int32_t width, int32_t height, int32_t i, int32_t j, int32_t k, uint64_t seed, int32_t max_depth, int32_t flags,
                   double* rows9_host, int32_t cap, int32_t* n_out_host);

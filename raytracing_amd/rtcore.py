@@ -321,7 +321,7 @@ def resolve(accum_ptr, is_fp64, n_pixels, spp, rgb_ptr, stream=None):
 
 
 def debug_libm(op, x, y):
-    """the device library's results for libm calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log; 7 sign of sin(x) as the checker texture takes it): rt_debug_libm"""
+    """the device library's results for libm calls (op 1 sin, 2 cos, 3 acos, 4 atan2(x, y), 5 pow(x, y), 6 log; 7 sign of sin(x) as the checker texture takes it, 8 x^5 as the dielectric's reflectance takes it): rt_debug_libm"""
     op = np.ascontiguousarray(op, dtype=np.int32); x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
     out = np.zeros(len(op))
     _check(load_library().rt_debug_libm(_ptr(op, C.c_int32), _ptr(x, C.c_double), _ptr(y, C.c_double), len(op), _ptr(out, C.c_double)))

@@ -7,6 +7,8 @@ a branch; fp32 mode is held to a stated relative-RMSE tolerance.
 """
 import os
 
+import math
+
 import numpy as np
 import pytest
 
@@ -598,6 +600,23 @@ def test_checker_sign_is_the_sign_of_the_library_sine(R):
     want = np.concatenate([np.sign(sn), want_tail])
     bad = np.flatnonzero(got != want)
     assert len(bad) == 0, [(float(x[i]).hex(), float(got[i]), float(want[i])) for i in bad[:8]]
+
+
+def test_fifth_power_of_the_dielectric_is_the_rounded_fifth_power(R):
+    """reflectance() (material.hpp:128-133) raises 1 - cos to the fifth power with pow(); the fp64 kernels take x^5 in double-double and
+    round once (rt_device.h pow5).  Through rt_debug_libm op 8: equal to the host's pow(x, 5) on >= 99.8 % of the arguments (glibc's pow is
+    itself not correctly rounded on a sliver of them), never more than one unit in the last place away; 0, 1, 2, NaN and tiny arguments
+    as pow() has them."""
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.uniform(0, 2, 300000), rng.uniform(0, 2, 100000) * np.exp2(-rng.integers(0, 40, 100000)), [0.0, 1.0, 2.0, 0.5, 1e-60, np.nan]])
+    got = R.debug_libm(np.full(len(x), 8), x, np.zeros(len(x)))
+    want = np.array([math.pow(v, 5.0) if v == v else math.nan for v in x])
+    fin = ~np.isnan(want)
+    assert np.isnan(got[~fin]).all()
+    assert float((got[fin] == want[fin]).mean()) >= 0.998
+    ulps = np.abs(got[fin].view(np.int64) - want[fin].view(np.int64))
+    assert int(ulps.max()) <= 1, int(ulps.max())
+    assert got[-6] == 0.0 and got[-5] == 1.0 and got[-4] == 32.0 and got[-3] == 0.03125
 
 
 def test_empty_work_is_well_defined(R, golden_dir):
