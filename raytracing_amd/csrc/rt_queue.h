@@ -66,7 +66,7 @@ __device__ inline void q_store_hit(QSlot<float>* s, float t, int32_t hit)
 __device__ inline void q_store_hit(QSlot<double>* s, double t, int32_t hit) { s->t = t; s->hit = hit; }
 
 template <typename R, bool kCount, bool kQuant, int kFull>
-__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32))
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 ? (kFull == 5 ? RT_WAVES_FP64_SPHERES : 3) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32))     // fp64: 3 waves (this kernel's slots spill 250-300 B at 128 VGPRs)
 render_queue_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters, QSlot<R>* __restrict__ pools,
                     unsigned int* __restrict__ pool_locks)
 {

@@ -22,15 +22,21 @@
 #pragma once
 
 #include "rt_device.h"
-// Waves per SIMD the variants are compiled for.  With the four-wide nodes a visit holds 16 node dwords and 24 plane distances, and
-// the OBJ-loader variants pay for registers rather than for occupancy: mesh workload, 4K, 64 spp, fp32 60.0 ms at 4 waves (128
-// VGPRs), 59.3 at 3; fp64 (rays, leaf tests and shading in double) 89.2 ms at 4, 82.9 at 3 (168 VGPRs), 105.8 at 2.  (Binary
-// 32-byte nodes, round 2 before the wide nodes: fp32 best at 5 waves / 96 VGPRs, fp64 at 4.)
+// Waves per SIMD the variants are compiled for.  With the four-wide nodes a visit holds 16 node dwords and 24 plane distances.  fp32: mesh
+// workload, 4K, 64 spp, 60.0 ms at 4 waves (128 VGPRs), 59.3 at 3.  fp64 (rays, leaf tests and shading in double): while the shade pass
+// carried the library's pow / sincos / sines inline, 3 waves (168 VGPRs) beat 4 (312 B of scratch per lane through the path the node
+// fetches use: +8 %, HISTORY); since their replacement the OBJ-loader variant needs 88 B at 128 VGPRs and 4 waves win: mesh 4K 128 spp
+// 152.7 -> 145.7 ms with the 31-entry stack budget that lets four workgroups share a CU's LDS (rtcore.hip builds the fp64 scene's wide
+// nodes to that budget).  The boxes-and-volumes twin of the spheres variant (6: the Cornell room) likewise: 198.0 -> 181.3 ms.  The
+// general variants (0, 1, 2) and the instanced twin (7) still spill 270-550 B at 128 VGPRs and stay at 3.
 #ifndef RT_WAVES_OBJ
 #define RT_WAVES_OBJ 4
 #endif
 #ifndef RT_WAVES_FP64_OBJ
-#define RT_WAVES_FP64_OBJ 3
+#define RT_WAVES_FP64_OBJ 4
+#endif
+#ifndef RT_WAVES_FP64_BOXES
+#define RT_WAVES_FP64_BOXES 4
 #endif
 #ifndef RT_WAVES_FP64
 #define RT_WAVES_FP64 3
@@ -221,7 +227,7 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
 
 // waves per SIMD a variant is compiled for
 template <typename R, int kFull> constexpr int wave_kernel_waves()
-{ return sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32; }
+{ return sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : kFull == 6 ? RT_WAVES_FP64_BOXES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32; }
 
 template <typename R, bool kCount, bool kQuant, int kFull, bool kSorted>
 __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const RenderArgs& a, R* __restrict__ accum, unsigned long long* __restrict__ counters)

@@ -43,6 +43,8 @@ template <typename R> struct DeviceScene {
     std::vector<void*> owned;
     uint32_t ops_bytes = 0, prims_bytes = 0;   // padded to 16
     std::vector<uint32_t> leaf_order;          // fp32 scene, during rt_scene_create only: primitive ids in the fast tree's leaf order
+    const rt::WNode* wnodes64 = nullptr;       // fp32 scene: the wide nodes the fp64 scene walks when its stack budget is the tighter one (else null: the same)
+    int32_t wide_stack64 = 0;
 };
 
 template <typename T> int upload(std::vector<void*>& owned, const std::vector<T>& host, const T** dev, size_t pad_to = 16)
@@ -378,7 +380,8 @@ template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const
     ordered.back() = dummy_record<double>();
     int rc;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
-    out.view.bnodes = tree->view.bnodes; out.view.wnodes = tree->view.wnodes; out.view.wide_stack = tree->view.wide_stack; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
+    out.view.bnodes = tree->view.bnodes; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
+    out.view.wnodes = tree->wnodes64 ? tree->wnodes64 : tree->view.wnodes; out.view.wide_stack = tree->wnodes64 ? tree->wide_stack64 : tree->view.wide_stack;
     out.view.sorted_visit = tree->view.sorted_visit;
     return RT_OK;
 }
@@ -430,27 +433,46 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     double radius = 0;
     for (const rt::BNode& n : nodes) for (int k = 0; k < 6; k++) { if (std::isfinite(n.lb[k])) radius = std::max(radius, (double) std::fabs(n.lb[k])); if (std::isfinite(n.rb[k])) radius = std::max(radius, (double) std::fabs(n.rb[k])); }
     const double pad = 8 * 1.2e-7 * std::max(radius, 1e-30);       // fp32 decode error of origin*idir - o*idir, in world units
-    // stack budget 35: 37 levels of LDS stack are what four fp32 workgroups (three fp64 ones) per CU leave room for; the mesh workload's
-    // tree (binary depth 24) collapses freely into 34.  A tighter budget keeps the tallest paths narrower: 30 -> 38 % more nodes, +5 % time
-    int budget = 35;
-    if (const char* e = std::getenv("RT_WIDE_STACK")) budget = std::max(1, std::atoi(e));
+    // stack budget: the LDS stack of a workgroup is one KiB per level, and four workgroups per CU (four waves per SIMD) must fit it beside
+    // their tile sums -- 35 entries (37 levels) for the fp32 kernels (3 KiB of sums), 31 (33 levels) for the fp64 ones (6 KiB), which run
+    // triangle scenes at four waves too since the shade pass's register diet (HISTORY, round 3).  The mesh workload's tree (binary depth 24)
+    // collapses freely into 34 entries; a tighter budget keeps the tallest paths narrower (31: +1.3 % time at equal occupancy, 30: 38 %
+    // more nodes, +5 %), so each precision gets the tree its own budget allows: the fp64 scene a second set of wide nodes when 35 is not
+    // enough for it (same binary tree, same leaf order and records).
+    int budget = 35, budget64 = 31;
+    if (const char* e = std::getenv("RT_WIDE_STACK")) budget = budget64 = std::max(1, std::atoi(e));
     const rtb::WideTree wt = rtb::widen(tree, budget);
     const int32_t dummy_leaf = ~(int32_t) ((uint32_t) tree.order.size() * 8u);      // leaf of one record: the one after the last real record
-    std::vector<rt::WNode> wn(wt.nodes.size());
-    for (size_t i = 0; i < wn.size(); i++) {
-        const rtb::WideNode& w = wt.nodes[i];
-        std::memset(&wn[i], 0, sizeof(rt::WNode));
-        for (int a = 0; a < 3; a++) {
-            double lo[4], hi[4];
-            for (int k = 0; k < w.n; k++) { lo[k] = (double) down(w.box[k].lo[a]) - pad; hi[k] = (double) up(w.box[k].hi[a]) + pad; }
-            rtb::quantise_axis_wide(lo, hi, w.n, wn[i].o[a], wn[i].lo[a], wn[i].hi[a]);
+    auto encode = [&](const rtb::WideTree& t) {
+        std::vector<rt::WNode> enc(t.nodes.size());
+        for (size_t i = 0; i < enc.size(); i++) {
+            const rtb::WideNode& w = t.nodes[i];
+            std::memset(&enc[i], 0, sizeof(rt::WNode));
+            for (int a = 0; a < 3; a++) {
+                double lo[4], hi[4];
+                for (int k = 0; k < w.n; k++) { lo[k] = (double) down(w.box[k].lo[a]) - pad; hi[k] = (double) up(w.box[k].hi[a]) + pad; }
+                rtb::quantise_axis_wide(lo, hi, w.n, enc[i].o[a], enc[i].lo[a], enc[i].hi[a]);
+            }
+            // an unused slot names the dummy leaf (one record that no ray can hit, appended to the record arrays below): its box decodes
+            // inside out (lo 255, hi 0) and is missed, but should rounding ever let a ray into it, the ray tests a triangle of zero area
+            // and walks on -- so the visit needs no validity test per child
+            for (int k = 0; k < 4; k++) enc[i].child[k] = k < w.n ? w.child[k] : dummy_leaf;
+            enc[i].n = (uint32_t) w.axis * 0x01010101u;      // as a v_perm_b32 selector: byte `axis` of its first operand, four times
+            enc[i].pad[0] = (uint32_t) w.n;
         }
-        // an unused slot names the dummy leaf (one record that no ray can hit, appended to the record arrays below): its box decodes
-        // inside out (lo 255, hi 0) and is missed, but should rounding ever let a ray into it, the ray tests a triangle of zero area
-        // and walks on -- so the visit needs no validity test per child
-        for (int k = 0; k < 4; k++) wn[i].child[k] = k < w.n ? w.child[k] : dummy_leaf;
-        wn[i].n = (uint32_t) w.axis * 0x01010101u;      // as a v_perm_b32 selector: byte `axis` of its first operand, four times
-        wn[i].pad[0] = (uint32_t) w.n;
+        return enc;
+    };
+    const std::vector<rt::WNode> wn = encode(wt);
+    out.wnodes64 = nullptr; out.wide_stack64 = wt.stack_need;
+    if (all_triangles && budget64 < budget && wt.stack_need > budget64 && tree.depth <= budget64) {
+        const rtb::WideTree wt64 = rtb::widen(tree, budget64);
+        if (wt64.stack_need < wt.stack_need) {
+            const std::vector<rt::WNode> wn64 = encode(wt64);
+            int rc64;
+            if ((rc64 = upload(out.owned, wn64, &out.wnodes64))) return rc64;
+            out.wide_stack64 = wt64.stack_need;
+            if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree of the fp64 kernels: %zu nodes, stack need %d entries\n", wn64.size(), wt64.stack_need);
+        }
     }
     // visiting order of the wide nodes (rt_bvh_build.h visit_order_census; scenes of triangles alone -- the ones that walk these nodes): slot
     // order unless it costs this tree's incoherent rays more than 5 % more box tests than the distance order does.  The two measured points
