@@ -915,7 +915,8 @@ template <> __device__ inline float checker_sine<float>(const vec3<float>& pos)
     return s(k * pos.x) * s(k * pos.y) * s(k * pos.z);
 }
 template <> __device__ inline bool checker_odd<float>(const vec3<float>& pos) { return checker_sine<float>(pos) < 0.0f; }
-// image_texture::value (texture.hpp:95-124)
+// image_texture::value (texture.hpp:95-124).  `pixels`: the texel bytes; the 256 entries of R in front of them hold pow(b / 255, 2.2) for
+// every byte b, computed by rt_scene_create with the host's pow (rtcore.hip build_device): a colour texel is three table reads
 template <typename R> __device__ inline vec3<R> tex_image(const uint8_t* __restrict__ pixels, const Tex<R>& t, R u, R v)
 {
     if (t.a <= 0) return vec3<R>(R(0), R(1), R(1));
@@ -925,15 +926,13 @@ template <typename R> __device__ inline vec3<R> tex_image(const uint8_t* __restr
     if (x >= t.a) x = t.a - 1;
     if (y >= t.b) y = t.b - 1;
     const uint8_t* b = pixels + t.offset + ((size_t) y * t.a * t.ch + (size_t) x * t.ch);
+    if (t.color_based) {
+        const R* __restrict__ decoded = reinterpret_cast<const R*>(pixels) - 256;
+        return vec3<R>(decoded[b[0]], decoded[b[1]], decoded[b[2]]);
+    }
     const R scale = R(1) / R(255);
-    vec3<R> c = scale * vec3<R>(R(b[0]), R(b[1]), R(b[2]));
-    if (t.color_based) return vec3<R>(rt_pow(c.x, R(2.2)), rt_pow(c.y, R(2.2)), rt_pow(c.z, R(2.2)));
-    return c;
+    return scale * vec3<R>(R(b[0]), R(b[1]), R(b[2]));
 }
-// ... out of line for the general scene classes: the texel address arithmetic and three pow() calls are bulk most of their shade passes
-// never run, and inlined they sit in the register allocation of every one (see checker_odd_library).  The OBJ-loader class keeps it
-// inline (kTex = 1 below: measured both ways)
-template <typename R> __device__ __attribute__((noinline)) vec3<R> tex_image_call(const uint8_t* __restrict__ pixels, const Tex<R>& t, R u, R v) { return tex_image<R>(pixels, t, u, v); }
 // kTex = 2: the scene holds no image texture; 1: it holds no checker (OBJ-loader scenes: rtcore.hip scene_kinds)
 template <typename R, int kTex = 0> __device__ inline vec3<R> tex_color(const Scene<R>& sc, int ti, const vec3<R>& pos, R u, R v)
 {
@@ -944,7 +943,7 @@ template <typename R, int kTex = 0> __device__ inline vec3<R> tex_color(const Sc
             ti = checker_odd(pos) ? t.a : t.b;
             continue;
         }
-        if (kTex != 2 && t.kind == RT_TEX_IMAGE) return kTex == 1 ? tex_image<R>(sc.pixels, t, u, v) : tex_image_call<R>(sc.pixels, t, u, v);
+        if (kTex != 2 && t.kind == RT_TEX_IMAGE) return tex_image<R>(sc.pixels, t, u, v);
         break;
     }
     return vec3<R>();

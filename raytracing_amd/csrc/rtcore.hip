@@ -579,7 +579,17 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         xforms[i].sn = (xforms[i].flags & RT_PRIM_FLAG_ROTATEY) ? (R) x[0] : R(0); xforms[i].cs = (xforms[i].flags & RT_PRIM_FLAG_ROTATEY) ? (R) x[1] : R(1);
         for (int k = 0; k < 3; k++) xforms[i].t[k] = (xforms[i].flags & RT_PRIM_FLAG_TRANSLATE) ? (R) x[2 + k] : R(0);
     }
-    std::vector<uint8_t> pixels(d->tex_pixels ? d->tex_pixels : nullptr, d->tex_pixels ? d->tex_pixels + d->n_pixel_bytes : nullptr);
+    // texel bytes, behind a table of the 256 values a colour texel can decode to (texture.hpp:117-121: pow(byte / 255, 2.2) per channel):
+    // computed HERE, with the host's pow -- the library the reference itself calls -- so a textured hit costs three loads instead of three
+    // device pow() (~600 vector instructions a shade pass), and carries the CPU path's bits exactly.  Scene::pixels points behind the table.
+    std::vector<uint8_t> pixels(256 * sizeof(R));
+    {
+        R lut[256];
+        const R scale = R(1) / R(255);
+        for (int b = 0; b < 256; b++) lut[b] = (R) std::pow(scale * R(b), R(2.2));
+        std::memcpy(pixels.data(), lut, sizeof lut);
+    }
+    if (d->tex_pixels) pixels.insert(pixels.end(), d->tex_pixels, d->tex_pixels + d->n_pixel_bytes);
     pixels.insert(pixels.end(), 4, (uint8_t) 0);    // a 1- or 2-channel image's last texel is read as three bytes (validate())
 
     rt::Scene<R>& v = out.view;
@@ -590,6 +600,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
     if ((rc = upload(out.owned, mats, &v.mats))) return rc;
     if ((rc = upload(out.owned, texs, &v.texs))) return rc;
     if ((rc = upload(out.owned, pixels, &v.pixels))) return rc;
+    v.pixels += 256 * sizeof(R);                    // behind the decode table (the allocation stays in out.owned)
     if ((rc = upload(out.owned, lights, &v.lights))) return rc;
     if (d->n_xforms) { if ((rc = upload(out.owned, xforms, &v.xforms))) return rc; } else v.xforms = nullptr;
     if (light_tri) { if ((rc = upload(out.owned, ltris, &v.light_tris))) return rc; } else v.light_tris = nullptr;
