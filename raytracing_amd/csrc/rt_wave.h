@@ -35,6 +35,9 @@
 #ifndef RT_WAVES_FP64_OBJ
 #define RT_WAVES_FP64_OBJ 4
 #endif
+#ifndef RT_WAVES_FP64_SORTED
+#define RT_WAVES_FP64_SORTED 3      // render_wave_sorted_kernel<double, ., 3>: the sparse soups keep the 35-entry tree, whose LDS stack three workgroups share (rtcore.hip)
+#endif
 #ifndef RT_WAVES_FP64_BOXES
 #define RT_WAVES_FP64_BOXES 4
 #endif
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(256, (wave_kernel_waves<R, kFull>())) render_w
 }
 // the same kernel over wide nodes whose hit children are visited by entry distance (Scene::sorted_visit: sparse soups)
 template <typename R, bool kCount, int kFull>
-__global__ void __launch_bounds__(256, (wave_kernel_waves<R, kFull>())) render_wave_sorted_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+__global__ void __launch_bounds__(256, (sizeof(R) == 8 && kFull == 3 ? RT_WAVES_FP64_SORTED : wave_kernel_waves<R, kFull>())) render_wave_sorted_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     render_wave_body<R, kCount, true, kFull, true>(sc, a, accum, counters);
 }

@@ -463,17 +463,6 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         return enc;
     };
     const std::vector<rt::WNode> wn = encode(wt);
-    out.wnodes64 = nullptr; out.wide_stack64 = wt.stack_need;
-    if (all_triangles && budget64 < budget && wt.stack_need > budget64 && tree.depth <= budget64) {
-        const rtb::WideTree wt64 = rtb::widen(tree, budget64);
-        if (wt64.stack_need < wt.stack_need) {
-            const std::vector<rt::WNode> wn64 = encode(wt64);
-            int rc64;
-            if ((rc64 = upload(out.owned, wn64, &out.wnodes64))) return rc64;
-            out.wide_stack64 = wt64.stack_need;
-            if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree of the fp64 kernels: %zu nodes, stack need %d entries\n", wn64.size(), wt64.stack_need);
-        }
-    }
     // visiting order of the wide nodes (rt_bvh_build.h visit_order_census; scenes of triangles alone -- the ones that walk these nodes): slot
     // order unless it costs this tree's incoherent rays more than 5 % more box tests than the distance order does.  The two measured points
     // -- mesh +1.8 % tests, -0.6 % time without the sort; 10 M-triangle soup +27 % tests, +9.6 % time -- put the break-even near +3 %
@@ -506,6 +495,20 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] visit order census: %.1f box tests per ray in slot order, %.1f by distance -> %s\n", tests[0], tests[1], out.view.sorted_visit ? "sorted" : "slot order");
     }
     if (const char* e = std::getenv("RT_SORTED_VISIT")) out.view.sorted_visit = std::atoi(e) != 0;
+    out.wnodes64 = nullptr; out.wide_stack64 = wt.stack_need;
+    // (not for the sparse soups the census sends to the distance-sorted visit: their deep trees lose far more to the tighter budget than a
+    // fourth wave returns -- 10 M-triangle soup, 8 spp: 173.9 ms on the 35-entry tree at three waves, 220.9 on the 31-entry one -- so
+    // render_wave_sorted_kernel<double> stays a three-wave kernel on the common tree)
+    if (all_triangles && !out.view.sorted_visit && budget64 < budget && wt.stack_need > budget64 && tree.depth <= budget64) {
+        const rtb::WideTree wt64 = rtb::widen(tree, budget64);
+        if (wt64.stack_need < wt.stack_need) {
+            const std::vector<rt::WNode> wn64 = encode(wt64);
+            int rc64;
+            if ((rc64 = upload(out.owned, wn64, &out.wnodes64))) return rc64;
+            out.wide_stack64 = wt64.stack_need;
+            if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree of the fp64 kernels: %zu nodes, stack need %d entries\n", wn64.size(), wt64.stack_need);
+        }
+    }
     if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree: %zu nodes of 64 B, stack need %d entries\n", wn.size(), wt.stack_need);
     if (wt.stack_need + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode wide tree needs a deeper traversal stack than RT_BVH_STACK_MAX");
     std::vector<rt::Prim<float>> ordered(tree.order.size() + 1);
