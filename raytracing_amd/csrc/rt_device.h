@@ -968,7 +968,7 @@ __device__ inline double pow5(double x)
     const double p1 = x * x, e1 = __builtin_fma(x, x, -p1);
     const double p2 = p1 * p1, e2 = __builtin_fma(p1, p1, -p2) + 2.0 * (p1 * e1);
     const double p3 = p2 * x, e3 = __builtin_fma(p2, x, -p3) + e2 * x;
-    return p3 + e3;
+    return p3 - p3 == 0.0 ? p3 + e3 : p3;              // p3 not finite (overflow, x = inf, NaN): the error terms are inf - inf; p3 is pow()'s answer
 }
 template <> __device__ inline double reflectance<double>(double cos_theta, double ior)
 {

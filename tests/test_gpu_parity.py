@@ -608,15 +608,15 @@ def test_fifth_power_of_the_dielectric_is_the_rounded_fifth_power(R):
     itself not correctly rounded on a sliver of them), never more than one unit in the last place away; 0, 1, 2, NaN and tiny arguments
     as pow() has them."""
     rng = np.random.default_rng(9)
-    x = np.concatenate([rng.uniform(0, 2, 300000), rng.uniform(0, 2, 100000) * np.exp2(-rng.integers(0, 40, 100000)), [0.0, 1.0, 2.0, 0.5, 1e-60, np.nan]])
+    x = np.concatenate([rng.uniform(0, 2, 300000), rng.uniform(0, 2, 100000) * np.exp2(-rng.integers(0, 40, 100000)), [0.0, 1.0, 2.0, 0.5, 1e-60, np.nan, np.inf, 3.5, 1e70]])
     got = R.debug_libm(np.full(len(x), 8), x, np.zeros(len(x)))
-    want = np.array([math.pow(v, 5.0) if v == v else math.nan for v in x])
+    want = np.array([(math.inf if v > 1e61 else math.pow(v, 5.0)) if v == v else math.nan for v in x])      # (math.pow raises on overflow)
     fin = ~np.isnan(want)
     assert np.isnan(got[~fin]).all()
     assert float((got[fin] == want[fin]).mean()) >= 0.998
     ulps = np.abs(got[fin].view(np.int64) - want[fin].view(np.int64))
     assert int(ulps.max()) <= 1, int(ulps.max())
-    assert got[-6] == 0.0 and got[-5] == 1.0 and got[-4] == 32.0 and got[-3] == 0.03125
+    assert got[-9] == 0.0 and got[-8] == 1.0 and got[-7] == 32.0 and got[-6] == 0.03125 and got[-3] == np.inf and got[-1] == np.inf
 
 
 def test_sine_and_cosine_of_the_cosine_lobe_stay_within_one_ulp_of_libm(R):
