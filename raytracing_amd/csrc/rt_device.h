@@ -905,7 +905,7 @@ template <typename R> __device__ inline bool checker_odd(const vec3<R>& pos)
     const bool zero = tx == R(0) || ty == R(0) || tz == R(0);                                                     // a factor +-0: the product is not < 0
     return !zero && (sine_negative(tx) != sine_negative(ty)) != sine_negative(tz);
 }
-template <typename R> __device__ inline R checker_sine(const vec3<R>& pos) { return rt_sin(R(10) * pos.x) * rt_sin(R(10) * pos.y) * rt_sin(R(10) * pos.z); }
+template <typename R> __device__ inline R checker_sine(const vec3<R>& pos);
 // fp32: only the sign is used.  The hardware sine takes revolutions and is exact enough after taking the fraction
 // (v_fract_f32 + v_sin_f32 instead of three range-reduced sinf calls, ~300 instructions).
 template <> __device__ inline float checker_sine<float>(const vec3<float>& pos)
@@ -1562,7 +1562,7 @@ __global__ void libm_kernel(const int32_t* __restrict__ op, const double* __rest
     case 2: r = rt_cos(x[idx]); break;
     case 3: r = rt_acos(x[idx]); break;
     case 4: r = rt_atan2(x[idx], y[idx]); break;
-    case 5: r = rt_pow(x[idx], y[idx]); break;
+    case 5: r = y[idx] == 5.0 ? pow5(x[idx]) : rt_pow(x[idx], y[idx]); break;      // (the one fifth power of a path is the dielectric's: what the kernels compute for it)
     case 6: r = rt_log(x[idx]); break;
     case 7: r = (double) sine_sign(x[idx]); break;
     case 8: r = pow5(x[idx]); break;
