@@ -155,6 +155,7 @@ template <typename R> struct Scene {
     const Tex<R>* texs;
     const uint8_t* pixels;
     const Prim<R>* lights; const TriShade<R>* light_tris; int32_t n_lights;
+    R n_lights_r, inv_n_lights;       // R(n_lights) and R(1) / R(n_lights) (group.hpp:107, :117), taken once by rt_scene_create: left to the kernels they are loop invariants held in vector registers for the whole launch
     int32_t need_uv;                  // some material reads uv (image texture)
     const BNode* bnodes; const Prim<R>* fprims; int32_t n_bnodes; int32_t bvh_depth;   // fast mode: SAH tree built by the library, records in leaf order
     const WNode* wnodes; int32_t wide_stack;   // the same tree collapsed to quantised four-wide nodes; stack entries a traversal of it can need
@@ -1199,7 +1200,7 @@ template <typename R, int kLight = 0> __device__ inline R light_pdf(const Scene<
 
 template <typename R, int kLight = 0> __device__ inline vec3<R> light_rand(const Scene<R>& sc, Rng& g, const vec3<R>& origin)
 {
-    int idx = (int) uniform<R>(g, R(0), R(sc.n_lights));                                    // group.hpp:117, util.hpp:42-45
+    int idx = (int) uniform<R>(g, R(0), sc.n_lights_r);                                     // group.hpp:117, util.hpp:42-45
     if (idx >= sc.n_lights) idx = sc.n_lights - 1;                                          // fp32 only: guards u*n rounding up to n
     const Prim<R>& p = sc.lights[idx];
     if (p.kind() == RT_PRIM_PLANEXZ) {                                                        // primitive.hpp:270-274
@@ -1218,7 +1219,7 @@ template <typename R, int kLight = 0> __device__ inline vec3<R> light_rand(const
 
 template <typename R, int kLight = 0> __device__ inline R lights_pdf(const Scene<R>& sc, const vec3<R>& origin, const vec3<R>& value, R len)
 {
-    R weight = R(1) / R(sc.n_lights);
+    R weight = sc.inv_n_lights;                                                             // 1.0 / objects.size(), group.hpp:107
     R avg = R(0);
     for (int i = 0; i < sc.n_lights; i++) avg += weight * light_pdf<R, kLight>(sc, i, origin, value, len);
     return avg;
@@ -1243,6 +1244,7 @@ template <typename R> __device__ inline Ray<R> camera_emit(const Camera<R>& c, R
 // ------------------------------------------------------------------ launch parameters shared with the host side
 struct RenderArgs {
     int32_t width, height, y_begin, y_end, spp_begin, spp_end, max_depth, flags;
+    double wm1, hm1;                           // double(width - 1), double(height - 1): the divisors of raytracing.cpp:102-103, converted once on the host
     uint64_t seed;
     uint32_t lds_ops_bytes, lds_prims_bytes;   // 0: read the traversal program from global memory
     uint32_t bvh_stack_levels;                 // > 0: fast mode, LDS stack of this many dwords per lane

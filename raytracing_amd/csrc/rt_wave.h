@@ -321,8 +321,8 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                     pixel_of(local, j, i);
                     if (j < a.width && i < a.y_end) {                                         // else: slot outside the image (edge tiles)
                         g.seed(a.seed, (uint32_t) (i * a.width + j), (uint32_t) k);
-                        R x = (R(j) + uniform<R>(g)) / R(a.width - 1);                          // raytracing.cpp:102-103
-                        R y = (R(i) + uniform<R>(g)) / R(a.height - 1);
+                        R x = (R(j) + uniform<R>(g)) / R(a.wm1);                                // raytracing.cpp:102-103
+                        R y = (R(i) + uniform<R>(g)) / R(a.hm1);
                         ray = camera_emit(sc.cam, g, x, y);
                         beta = vec3<R>(R(1), R(1), R(1));
                         depth = a.max_depth;

@@ -613,6 +613,7 @@ template <typename R> int build_device(const rt_scene_desc* d, const Flat& f, De
         if ((rc = upload(out.owned, rank, &v.ref_rank))) return rc;
     }
     v.n_ops = n_ops; v.n_prims = d->n_prims; v.n_lights = d->n_lights; v.need_uv = need_uv;
+    v.n_lights_r = R(d->n_lights); v.inv_n_lights = R(1) / R(d->n_lights);        // (no lights: inf, as the reference's 1.0 / 0; rt_render refuses such a scene)
     const double* c = d->camera;
     auto v3 = [&](int o) { return rt::vec3<R>((R) c[o], (R) c[o + 1], (R) c[o + 2]); };
     v.cam.pos = v3(0); v.cam.left_bottom = v3(3); v.cam.horizontal = v3(6); v.cam.vertical = v3(9); v.cam.u = v3(12); v.cam.v = v3(15);
@@ -795,6 +796,7 @@ int rt_render(rt_scene* s, const rt_render_params* p, void* accum_dev, rt_render
     hipStream_t st = static_cast<hipStream_t>(p->stream);
     rt::RenderArgs a{};
     a.width = p->width; a.height = p->height; a.y_begin = p->y_begin; a.y_end = p->y_end;
+    a.wm1 = (double) (p->width - 1); a.hm1 = (double) (p->height - 1);
     a.spp_begin = p->spp_begin; a.spp_end = p->spp_end; a.max_depth = p->max_depth; a.flags = p->flags; a.seed = p->seed;
     a.trav_keep = s->trav_keep; a.node_keep = s->node_keep; a.regen_min = s->regen_min; a.quantised = s->quantised; a.xcd_tiles = s->xcd_tiles; a.kinds = scene_kinds(s);
     if (p->mode == RT_MODE_FAST_FP32 && (p->flags & RT_FLAG_WAVEFRONT)) {
