@@ -312,7 +312,8 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                 unsigned int base = 0;
                 if (lane == leader) base = atomicAdd(item_counter, (unsigned int) __popcll(want));
                 base = __shfl(base, leader, 64);
-                const unsigned int item = base + (unsigned int) __popcll(want & ((1ull << lane) - 1ull));
+                // fetching lanes below this one: v_mbcnt counts them (the mask (1 << lane) - 1 would be a 64-bit loop invariant held per lane)
+                const unsigned int item = base + __builtin_amdgcn_mbcnt_hi((unsigned int) (want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) want, 0u));
                 if (item >= n_items) finished = true;
                 else {
                     local = (int) (item & 255u);
