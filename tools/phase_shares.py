@@ -2,7 +2,7 @@
 """Where the wave kernel's time goes, from its own counters (RT_FLAG_COUNT_TESTS): share of the wave time per phase (regenerate, node
 loop, leaf step, shade), lane utilisation of the node loop and the leaf step, tests per traced ray.
 
-    python tools/phase_shares.py [obj|spheres|deep] [--mode fp64|fp32] [--spp 8] [--width 3840 --height 2160]
+    python tools/phase_shares.py [obj|spheres|deep|features|mixed|instanced|textured|smoke|cornell] [--mode fp64|fp32] [--spp 8] [--width 3840 --height 2160]
 """
 import argparse
 import os
@@ -30,6 +30,8 @@ if args.which == "obj":
     hs = HostScene.obj(path, w, h, 1, cam_pos=(0, 1.8, 5.0), cam_lookat=(0, 1.0, 0), fov=40.0)
 elif args.which == "deep":
     hs = HostScene.deep_bounce(w, h, 1)
+elif args.which in ("features", "mixed", "instanced", "textured", "smoke", "cornell"):
+    hs = getattr(HostScene, "features_lit" if args.which == "features" else args.which)(w, h)
 else:
     hs = HostScene.random_spheres(w, h, 1)
 sc = hs.upload()
