@@ -493,6 +493,45 @@ def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     osc.free()
 
 
+def test_triangle_scene_with_a_checker_takes_the_general_kernel(R, golden_dir):
+    """The OBJ-loader kernel variant (class 3) is compiled without the checker texture's code: the loader never makes one.  A description
+    that does hold one -- triangles, phong materials and a checker on one of them -- must fall to the general variant and render what
+    the reference mode renders (same streams, every pixel to 1e-12 of the frame's scale), checker included."""
+    g, m = load(golden_dir, "obj")
+    osc = SCENES["obj"][1](golden_dir, m)
+    d = dict(osc.export())
+    plain = R.Scene(d)
+    assert plain.kernel_name(R.MODE_FAST_FP64).rstrip(">").endswith("3"), plain.kernel_name(R.MODE_FAST_FP64)
+    plain.destroy()
+    nt = len(d["tex_kind"])
+    stride = np.asarray(d["tex_data"]).reshape(nt, -1).shape[1] if nt else 8
+    tex = np.zeros((nt + 3, stride))
+    if nt:
+        tex[:nt] = np.asarray(d["tex_data"]).reshape(nt, stride)
+    tex[nt, :3] = (0.9, 0.1, 0.1)                       # even
+    tex[nt + 1, :3] = (0.1, 0.1, 0.9)                   # odd
+    tex[nt + 2, :2] = (nt, nt + 1)                      # the checker over them
+    d["tex_kind"] = np.concatenate([np.asarray(d["tex_kind"], dtype=np.int32), np.array([1, 1, 2], dtype=np.int32)])
+    d["tex_data"] = tex
+    mt = np.array(d["mat_tex"], dtype=np.int32)
+    diffuse = [i for i in range(len(mt)) if np.asarray(d["mat_data"]).reshape(len(mt), -1)[i, 7:10].max() == 0]      # not the emitter
+    assert diffuse
+    for i in diffuse:
+        mt[i] = nt + 2
+    d["mat_tex"] = mt
+    sc = R.Scene(d)
+    assert sc.kernel_name(R.MODE_FAST_FP64).rstrip(">").endswith("0"), sc.kernel_name(R.MODE_FAST_FP64)
+    w, h = m["width"], m["height"]
+    fast, _, sf = sc.render_to_host(w, h, 0, 8, 12, R.MODE_FAST_FP64, seed=5)
+    ref, _, sr = sc.render_to_host(w, h, 0, 8, 12, R.MODE_REFERENCE_FP64, seed=5)
+    assert sf["rays"] == sr["rays"] and sf["rejected"] == sr["rejected"]
+    assert float(np.abs(fast - ref).max()) <= 1e-12 * max(float(np.abs(ref).max()), 1.0)
+    red_blue = np.abs(ref[..., 0] - ref[..., 2]) > 1e-3 * float(np.abs(ref).max())
+    assert red_blue.mean() > 0.02, "the checker's two colours should show in the frame"
+    sc.destroy()
+    osc.free()
+
+
 @pytest.mark.parametrize("name", ["obj", "ngon"])
 def test_both_visiting_orders_of_the_wide_nodes_find_the_same_hits(R, golden_dir, monkeypatch, name):
     """The wide nodes are visited in slot order (children stored sorted along one axis; the default for surface meshes) or with the hit
