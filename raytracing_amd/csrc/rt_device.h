@@ -987,10 +987,10 @@ template <> __device__ inline float reflectance<float>(float cos_theta, float io
     return r + (1.0f - r) * (x2 * x2 * x);
 }
 
-template <typename R> __device__ inline vec3<R> glass_dir(Rng& g, const Ray<R>& wi, const Hit<R>& h, R ior)            // material.hpp:109-122
+// `next`: normalize(wi.d), taken once for the metal and the dielectric lanes of a shade pass (mat_scatter)
+template <typename R> __device__ inline vec3<R> glass_dir(Rng& g, const vec3<R>& next, const Hit<R>& h, R ior)         // material.hpp:109-122
 {
     R ratio = h.front ? (R(1) / ior) : ior;
-    vec3<R> next = normalize(wi.d);
     R cos_theta = rt_min(dot(-next, h.normal), R(1));
     R sin_theta = rt_sqrt(R(1) - cos_theta * cos_theta);
     bool not_refract = ratio * sin_theta > R(1);
@@ -1031,6 +1031,10 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
                                                          vec3<R>& dir, bool& dir_set, vec3<R>& att, bool& spec, bool fixed = false)
 {
     dir_set = true;
+    // the incoming direction's unit vector, once for the metal and the dielectric lanes of the pass (a wave runs both branches whenever it
+    // holds both kinds: one root and one division instead of two of each)
+    vec3<R> unit_in;
+    if (kMat != 1 && (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC)) unit_in = normalize(wi.d);
     switch (kMat == 1 ? RT_MAT_PHONG : m.kind) {
     case RT_MAT_LAMBERTIAN:                                                                 // material.hpp:29-35
         spec = false;
@@ -1038,7 +1042,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         att = texc;
         return true;
     case RT_MAT_METAL: {                                                                    // material.hpp:74-82
-        vec3<R> next = reflect(normalize(wi.d), h.normal);
+        vec3<R> next = reflect(unit_in, h.normal);
         vec3<R> fuzz = m.d[0] * random_sphere<R>(g);
         dir = next + fuzz;
         att = texc;
@@ -1049,7 +1053,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
     case RT_MAT_DIELECTRIC:                                                                 // material.hpp:105-125
         spec = true;
         att = vec3<R>(R(1), R(1), R(1));
-        dir = glass_dir(g, wi, h, m.d[0]);
+        dir = glass_dir(g, unit_in, h, m.d[0]);
         return true;
     case RT_MAT_FOG:                                                                        // material.hpp:174-180; pdf() stays the base class's 0 (:14)
         if constexpr (kMat == 2) return false;
@@ -1070,7 +1074,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_scatter(Rng& g, c
         if (nz3(m.d + 10)) {
             spec = true;
             att = vec3<R>(m.d[10], m.d[11], m.d[12]);
-            dir = glass_dir(g, wi, h, m.d[14]);
+            dir = glass_dir(g, normalize(wi.d), h, m.d[14]);
             return true;
         }
         spec = false;
@@ -1106,7 +1110,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, c
     case RT_MAT_DIELECTRIC:
         spec = true;
         att = vec3<R>(R(1), R(1), R(1));
-        wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[0]); wo.time = wi.time;
+        wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, normalize(wi.d), h, m.d[0]); wo.time = wi.time;
         return true;
     case RT_MAT_PHONG: {
         if (nz3(m.d + 7)) return false;
@@ -1115,7 +1119,7 @@ template <typename R, int kMat = 0> __device__ inline bool mat_shading(Rng& g, c
         if (nz3(m.d + 10)) {
             spec = true;
             att = vec3<R>(m.d[10], m.d[11], m.d[12]);
-            wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, wi, h, m.d[14]); wo.time = wi.time;
+            wo.o = h.pos; wo.from = h.id; wo.d = glass_dir(g, normalize(wi.d), h, m.d[14]); wo.time = wi.time;
             return true;
         }
         spec = false;
