@@ -105,7 +105,9 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     if (a.bvh_stack_levels > 0) { trav = 2; region = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t); }
 #endif
     if (trav == 0 && a.lds_ops_bytes + a.lds_prims_bytes > 0) { trav = 1; region = (size_t) a.lds_ops_bytes + a.lds_prims_bytes; }
-    const size_t tile_bytes = (sizeof(RT_REAL) == sizeof(float) || trav == 2) ? 768 * sizeof(RT_REAL) + 16 : 0;
+    // (the fp64 OBJ-loader wave kernels keep no tile sums: rt_wave.h wave_global_sums)
+    const bool global_sums = trav == 2 && sizeof(RT_REAL) == 8 && a.kinds == 3 && !(a.flags & RT_FLAG_LEGACY_LOOP) && !(a.q_slots > 0 && q_pools && q_locks);
+    const size_t tile_bytes = global_sums ? 16 : (sizeof(RT_REAL) == sizeof(float) || trav == 2) ? 768 * sizeof(RT_REAL) + 16 : 0;
     a.lds_tile_offset = (uint32_t) region;
     const size_t lds = region + tile_bytes;
 #ifdef RT_WITH_WAVE
@@ -126,6 +128,10 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
         if (a.kinds == 6) return launch_wave<RT_REAL, false, 6>(count, grid, lds, s, sc, a, accum, counters);          // ... with boxes or volumes
         if (a.kinds == 7) return launch_wave<RT_REAL, false, 7>(count, grid, lds, s, sc, a, accum, counters);          // ... with instances
         if (a.kinds == 3) {
+            if (global_sums && !(a.flags & RT_FLAG_ACCUMULATE)) {      // the kernel only adds: the rows it renders start from zero
+                const hipError_t e = hipMemsetAsync(accum + (size_t) a.y_begin * a.width * 3, 0, (size_t) (a.y_end - a.y_begin) * a.width * 3 * sizeof(RT_REAL), s);
+                if (e != hipSuccess) return e;
+            }
             if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 3>(count, grid, lds, s, sc, a, accum, counters);
             if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
             return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);

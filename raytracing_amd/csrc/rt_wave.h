@@ -36,7 +36,7 @@
 #define RT_WAVES_FP64_OBJ 4
 #endif
 #ifndef RT_WAVES_FP64_SORTED
-#define RT_WAVES_FP64_SORTED 3      // render_wave_sorted_kernel<double, ., 3>: the sparse soups keep the 35-entry tree, whose LDS stack three workgroups share (rtcore.hip)
+#define RT_WAVES_FP64_SORTED 4      // render_wave_sorted_kernel<double, ., 3>: the sparse soups
 #endif
 #ifndef RT_WAVES_FP64_BOXES
 #define RT_WAVES_FP64_BOXES 4
@@ -228,6 +228,13 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
     }
 }
 
+// fp64 OBJ-loader variants: finished paths add their radiance to the frame buffer with global fp64 atomics instead of to per-workgroup tile
+// sums in LDS.  The 6 KiB of sums were what kept a fourth workgroup out of a CU's LDS beside a 37-level stack: without them the fp64 scene
+// walks the same 35-entry tree as the fp32 one at four waves per SIMD (rt_launch.h wave_global_sums is the host's copy of this rule:
+// rt_render clears the rows first unless RT_FLAG_ACCUMULATE).  Most paths end black and add nothing; the additions of a pixel come from one
+// workgroup and stay in its XCD's L2.  (LDS sums were already added in whatever order the waves finished: no order is lost.)
+template <typename R, int kFull> constexpr bool wave_global_sums() { return sizeof(R) == 8 && class_is_obj(kFull); }
+
 // waves per SIMD a variant is compiled for
 template <typename R, int kFull> constexpr int wave_kernel_waves()
 { return sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : kFull == 6 ? RT_WAVES_FP64_BOXES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32; }
@@ -263,9 +270,10 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t stack_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) smem + threadIdx.x * 4u;
     auto stack_at = [&](uint32_t lds_address) -> lds_u32& { return *(lds_u32*) (uintptr_t) lds_address; };
+    constexpr bool kGlobalSums = wave_global_sums<R, kFull>();
     R* tile_sum = reinterpret_cast<R*>(smem + a.lds_tile_offset);
-    unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + 768);
-    tile_sum[threadIdx.x * 3] = R(0); tile_sum[threadIdx.x * 3 + 1] = R(0); tile_sum[threadIdx.x * 3 + 2] = R(0);
+    unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + (kGlobalSums ? 0 : 768));
+    if constexpr (!kGlobalSums) { tile_sum[threadIdx.x * 3] = R(0); tile_sum[threadIdx.x * 3 + 1] = R(0); tile_sum[threadIdx.x * 3 + 2] = R(0); }
     if (threadIdx.x == 0) { item_counter[0] = 0u; item_counter[1] = 0u; }     // [1]: waves of this workgroup that have finished
     stack_at(stack_base) = (uint32_t) RT_BVH_SENTINEL;
     __syncthreads();
@@ -470,10 +478,18 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                 rejected_now = bad;
                 if (a.flags & RT_FLAG_DEBUG_RAY_COUNTS) { L = vec3<R>(R(path_rays), bad ? R(1) : R(0), R(0)); bad = false; }
                 if (!bad && (L.x != R(0) || L.y != R(0) || L.z != R(0))) {     // most paths end black (a miss, the depth limit): nothing to add
+                    if constexpr (kGlobalSums) {
+                        int pj, pi;
+                        pixel_of(local, pj, pi);
+                        R* dst = accum + ((size_t) pi * a.width + pj) * 3;
+                        unsafeAtomicAdd(dst, L.x); unsafeAtomicAdd(dst + 1, L.y); unsafeAtomicAdd(dst + 2, L.z);     // global_atomic_add_f64, no return
+                    }
+                    else {
                     R* dst = tile_sum + local * 3;
                     __hip_atomic_fetch_add(dst, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(dst + 1, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(dst + 2, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             else trav_begin(tv, best, ray, stack_base);
@@ -514,7 +530,7 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
             }
         }
     }
-    else {
+    else if constexpr (!kGlobalSums) {
         __syncthreads();
         int j, i;
         pixel_of((int) threadIdx.x, j, i);

@@ -433,13 +433,12 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     double radius = 0;
     for (const rt::BNode& n : nodes) for (int k = 0; k < 6; k++) { if (std::isfinite(n.lb[k])) radius = std::max(radius, (double) std::fabs(n.lb[k])); if (std::isfinite(n.rb[k])) radius = std::max(radius, (double) std::fabs(n.rb[k])); }
     const double pad = 8 * 1.2e-7 * std::max(radius, 1e-30);       // fp32 decode error of origin*idir - o*idir, in world units
-    // stack budget: the LDS stack of a workgroup is one KiB per level, and four workgroups per CU (four waves per SIMD) must fit it beside
-    // their tile sums -- 35 entries (37 levels) for the fp32 kernels (3 KiB of sums), 31 (33 levels) for the fp64 ones (6 KiB), which run
-    // triangle scenes at four waves too since the shade pass's register diet (HISTORY, round 3).  The mesh workload's tree (binary depth 24)
-    // collapses freely into 34 entries; a tighter budget keeps the tallest paths narrower (31: +1.3 % time at equal occupancy, 30: 38 %
-    // more nodes, +5 %), so each precision gets the tree its own budget allows: the fp64 scene a second set of wide nodes when 35 is not
-    // enough for it (same binary tree, same leaf order and records).
-    int budget = 35, budget64 = 31;
+    // stack budget 35: the LDS stack of a workgroup is one KiB per level, and four workgroups per CU (four waves per SIMD) must fit it: 37
+    // levels beside the fp32 kernels' 3 KiB of tile sums; the fp64 OBJ-loader kernels keep no tile sums (rt_wave.h wave_global_sums) and fit
+    // the same tree.  The mesh workload's tree (binary depth 24) collapses freely into 34 entries; a tighter budget keeps the tallest paths
+    // narrower (31: 27 % more nodes, +1.3 % time at equal occupancy -- and +27 % time on the 10 M-triangle soup's deep tree; 30: +5 %).
+    // (budget64: a separate, tighter tree for the fp64 scene -- what the fp64 kernels needed while they kept 6 KiB of sums in LDS; equal now.)
+    int budget = 35, budget64 = 35;
     if (const char* e = std::getenv("RT_WIDE_STACK")) budget = budget64 = std::max(1, std::atoi(e));
     const rtb::WideTree wt = rtb::widen(tree, budget);
     const int32_t dummy_leaf = ~(int32_t) ((uint32_t) tree.order.size() * 8u);      // leaf of one record: the one after the last real record
