@@ -106,7 +106,7 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
 #endif
     if (trav == 0 && a.lds_ops_bytes + a.lds_prims_bytes > 0) { trav = 1; region = (size_t) a.lds_ops_bytes + a.lds_prims_bytes; }
     // (the fp64 OBJ-loader wave kernels keep no tile sums: rt_wave.h wave_global_sums)
-    const bool global_sums = trav == 2 && sizeof(RT_REAL) == 8 && a.kinds == 3 && !(a.flags & RT_FLAG_LEGACY_LOOP) && !(a.q_slots > 0 && q_pools && q_locks);
+    const bool global_sums = trav == 2 && a.kinds == 3 && !(a.flags & RT_FLAG_LEGACY_LOOP) && !(a.q_slots > 0 && q_pools && q_locks);
     const size_t tile_bytes = global_sums ? 16 : (sizeof(RT_REAL) == sizeof(float) || trav == 2) ? 768 * sizeof(RT_REAL) + 16 : 0;
     a.lds_tile_offset = (uint32_t) region;
     const size_t lds = region + tile_bytes;

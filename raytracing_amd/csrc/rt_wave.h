@@ -25,10 +25,10 @@
 // Waves per SIMD the variants are compiled for.  With the four-wide nodes a visit holds 16 node dwords and 24 plane distances.  fp32: mesh
 // workload, 4K, 64 spp, 60.0 ms at 4 waves (128 VGPRs), 59.3 at 3.  fp64 (rays, leaf tests and shading in double): while the shade pass
 // carried the library's pow / sincos / sines inline, 3 waves (168 VGPRs) beat 4 (312 B of scratch per lane through the path the node
-// fetches use: +8 %, HISTORY); since their replacement the OBJ-loader variant needs 88 B at 128 VGPRs and 4 waves win: mesh 4K 128 spp
-// 152.7 -> 145.7 ms with the 31-entry stack budget that lets four workgroups share a CU's LDS (rtcore.hip builds the fp64 scene's wide
-// nodes to that budget).  The boxes-and-volumes twin of the spheres variant (6: the Cornell room) likewise: 198.0 -> 181.3 ms.  The
-// general variants (0, 1, 2) and the instanced twin (7) still spill 270-550 B at 128 VGPRs and stay at 3.
+// fetches use: +8 %, HISTORY); since their replacement the OBJ-loader variant needs ~56 B at 128 VGPRs and 4 waves win: mesh 4K 128 spp
+// 152.7 -> 145.7 ms.  Four workgroups must also share a CU's LDS: the OBJ-loader kernels keep no tile sums there (wave_global_sums
+// below), so a 37-entry tree's 39-level stack fits four times.  The boxes-and-volumes twin of the spheres variant (6: the Cornell
+// room) likewise: 198.0 -> 181.3 ms.  The general variants (0, 1, 2) and the instanced twin (7) still spill 220-480 B at 128 VGPRs: 3.
 #ifndef RT_WAVES_OBJ
 #define RT_WAVES_OBJ 4
 #endif
@@ -228,12 +228,13 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
     }
 }
 
-// fp64 OBJ-loader variants: finished paths add their radiance to the frame buffer with global fp64 atomics instead of to per-workgroup tile
-// sums in LDS.  The 6 KiB of sums were what kept a fourth workgroup out of a CU's LDS beside a 37-level stack: without them the fp64 scene
-// walks the same 35-entry tree as the fp32 one at four waves per SIMD (rt_launch.h wave_global_sums is the host's copy of this rule:
-// rt_render clears the rows first unless RT_FLAG_ACCUMULATE).  Most paths end black and add nothing; the additions of a pixel come from one
-// workgroup and stay in its XCD's L2.  (LDS sums were already added in whatever order the waves finished: no order is lost.)
-template <typename R, int kFull> constexpr bool wave_global_sums() { return sizeof(R) == 8 && class_is_obj(kFull); }
+// OBJ-loader variants: finished paths add their radiance to the frame buffer with global atomics instead of to per-workgroup tile sums in
+// LDS.  The sums (6 KiB in fp64, 3 in fp32) were what kept a fourth workgroup out of a CU's LDS beside a deep tree's stack: without them a
+// 37-entry stack budget (39 levels, 39 KiB) fits four times, in both precisions (launch_render keeps the host's copy of this rule and clears
+// the rows first unless RT_FLAG_ACCUMULATE).  Most paths end black and add nothing; the additions of a pixel come from one workgroup and stay
+// in its XCD's L2.  (LDS sums were already added in whatever order the waves finished: no order is lost.)  10 M-triangle soup: fp64
+// 0.91 -> 1.11 Grays/s, fp32 0.98 -> 1.22; mesh fp64 unchanged, fp32 +2 % time.
+template <typename R, int kFull> constexpr bool wave_global_sums() { return class_is_obj(kFull); }
 
 // waves per SIMD a variant is compiled for
 template <typename R, int kFull> constexpr int wave_kernel_waves()

@@ -43,8 +43,6 @@ template <typename R> struct DeviceScene {
     std::vector<void*> owned;
     uint32_t ops_bytes = 0, prims_bytes = 0;   // padded to 16
     std::vector<uint32_t> leaf_order;          // fp32 scene, during rt_scene_create only: primitive ids in the fast tree's leaf order
-    const rt::WNode* wnodes64 = nullptr;       // fp32 scene: the wide nodes the fp64 scene walks when its stack budget is the tighter one (else null: the same)
-    int32_t wide_stack64 = 0;
 };
 
 template <typename T> int upload(std::vector<void*>& owned, const std::vector<T>& host, const T** dev, size_t pad_to = 16)
@@ -380,8 +378,7 @@ template <> int build_fast_tree<double>(const rt_scene_desc*, const Flat&, const
     ordered.back() = dummy_record<double>();
     int rc;
     if ((rc = upload(out.owned, ordered, &out.view.fprims))) return rc;
-    out.view.bnodes = tree->view.bnodes; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
-    out.view.wnodes = tree->wnodes64 ? tree->wnodes64 : tree->view.wnodes; out.view.wide_stack = tree->wnodes64 ? tree->wide_stack64 : tree->view.wide_stack;
+    out.view.bnodes = tree->view.bnodes; out.view.wnodes = tree->view.wnodes; out.view.wide_stack = tree->view.wide_stack; out.view.n_bnodes = tree->view.n_bnodes; out.view.bvh_depth = tree->view.bvh_depth;
     out.view.sorted_visit = tree->view.sorted_visit;
     return RT_OK;
 }
@@ -433,13 +430,13 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
     double radius = 0;
     for (const rt::BNode& n : nodes) for (int k = 0; k < 6; k++) { if (std::isfinite(n.lb[k])) radius = std::max(radius, (double) std::fabs(n.lb[k])); if (std::isfinite(n.rb[k])) radius = std::max(radius, (double) std::fabs(n.rb[k])); }
     const double pad = 8 * 1.2e-7 * std::max(radius, 1e-30);       // fp32 decode error of origin*idir - o*idir, in world units
-    // stack budget 35: the LDS stack of a workgroup is one KiB per level, and four workgroups per CU (four waves per SIMD) must fit it: 37
-    // levels beside the fp32 kernels' 3 KiB of tile sums; the fp64 OBJ-loader kernels keep no tile sums (rt_wave.h wave_global_sums) and fit
-    // the same tree.  The mesh workload's tree (binary depth 24) collapses freely into 34 entries; a tighter budget keeps the tallest paths
-    // narrower (31: 27 % more nodes, +1.3 % time at equal occupancy -- and +27 % time on the 10 M-triangle soup's deep tree; 30: +5 %).
-    // (budget64: a separate, tighter tree for the fp64 scene -- what the fp64 kernels needed while they kept 6 KiB of sums in LDS; equal now.)
-    int budget = 35, budget64 = 35;
-    if (const char* e = std::getenv("RT_WIDE_STACK")) budget = budget64 = std::max(1, std::atoi(e));
+    // stack budget: the LDS stack of a workgroup is one KiB per level, and four workgroups per CU (four waves per SIMD) must fit it -- 37
+    // levels (35 entries) beside the 3 KiB of tile sums of the fp32 kernels; the OBJ-loader kernels keep no sums in LDS (rt_wave.h
+    // wave_global_sums) and take 39 levels (37 entries).  The mesh workload's tree (binary depth 24) collapses freely into 34 entries; a
+    // tighter budget keeps the tallest paths narrower (31: 27 % more nodes, +1.3 % time at equal occupancy -- and +27 % time on the
+    // 10 M-triangle soup's deep tree, which still gains 6 % from 35 -> 37).
+    int budget = all_triangles ? 37 : 35;
+    if (const char* e = std::getenv("RT_WIDE_STACK")) budget = std::max(1, std::atoi(e));
     const rtb::WideTree wt = rtb::widen(tree, budget);
     const int32_t dummy_leaf = ~(int32_t) ((uint32_t) tree.order.size() * 8u);      // leaf of one record: the one after the last real record
     auto encode = [&](const rtb::WideTree& t) {
@@ -494,20 +491,6 @@ template <> int build_fast_tree<float>(const rt_scene_desc* d, const Flat& f, co
         if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] visit order census: %.1f box tests per ray in slot order, %.1f by distance -> %s\n", tests[0], tests[1], out.view.sorted_visit ? "sorted" : "slot order");
     }
     if (const char* e = std::getenv("RT_SORTED_VISIT")) out.view.sorted_visit = std::atoi(e) != 0;
-    out.wnodes64 = nullptr; out.wide_stack64 = wt.stack_need;
-    // (not for the sparse soups the census sends to the distance-sorted visit: their deep trees lose far more to the tighter budget than a
-    // fourth wave returns -- 10 M-triangle soup, 8 spp: 173.9 ms on the 35-entry tree at three waves, 220.9 on the 31-entry one -- so
-    // render_wave_sorted_kernel<double> stays a three-wave kernel on the common tree)
-    if (all_triangles && !out.view.sorted_visit && budget64 < budget && wt.stack_need > budget64 && tree.depth <= budget64) {
-        const rtb::WideTree wt64 = rtb::widen(tree, budget64);
-        if (wt64.stack_need < wt.stack_need) {
-            const std::vector<rt::WNode> wn64 = encode(wt64);
-            int rc64;
-            if ((rc64 = upload(out.owned, wn64, &out.wnodes64))) return rc64;
-            out.wide_stack64 = wt64.stack_need;
-            if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree of the fp64 kernels: %zu nodes, stack need %d entries\n", wn64.size(), wt64.stack_need);
-        }
-    }
     if (std::getenv("RT_DEBUG")) fprintf(stderr, "[rtcore] wide tree: %zu nodes of 64 B, stack need %d entries\n", wn.size(), wt.stack_need);
     if (wt.stack_need + 2 > RT_BVH_STACK_MAX) return fail(RT_EUNSUPPORTED, "fast-mode wide tree needs a deeper traversal stack than RT_BVH_STACK_MAX");
     std::vector<rt::Prim<float>> ordered(tree.order.size() + 1);
