@@ -127,8 +127,8 @@ typedef struct rt_scene_desc {
                                     walk visits last, and so does this mode (ties are broken by the primitives' rank in the reference's
                                     visit order; the one known residue: walls shared by two neighbouring `box` primitives).  Volumes draw
                                     random numbers inside the traversal, so their streams follow the visit order.  accum_dev is double;
-                                    sums are added per tile in completion order, so they match the reference mode's to rounding
-                                    of the additions, not bit for bit.  Zero-direction rays (phong) against spheres
+                                    sums are added per tile (per pixel for scenes of triangles alone) in completion order, so they match the
+                                    reference mode's to rounding of the additions, not bit for bit.  Zero-direction rays (phong) against spheres
                                     follow the reference's NaN slabs only in RT_MODE_REFERENCE_FP64. */
 
 #define RT_FLAG_ACCUMULATE 1     /* add this call's sample sums into accum_dev instead of overwriting it */
@@ -193,7 +193,9 @@ int rt_scene_destroy(rt_scene* scene);
 /* Renders samples [spp_begin, spp_end) of rows [y_begin, y_end): per pixel the SUM over those samples of
  * trace(emit(x, y)) with rejected samples zeroed -- the body of the k-loop at raytracing.cpp:101-113.
  * accum_dev: width*height*3 sums, row i = image row i as in the reference (row 0 is the bottom of the PNG),
- * double for RT_MODE_REFERENCE_FP64 and RT_MODE_FAST_FP64, float for the fp32 modes.  One kernel, asynchronous on params->stream unless
+ * double for RT_MODE_REFERENCE_FP64 and RT_MODE_FAST_FP64, float for the fp32 modes.  It must be ordinary device memory (hipMalloc / a torch
+ * CUDA tensor), not host-mapped or fine-grained memory: for scenes of triangles alone the fast modes add each finished path into it with
+ * the GPU's floating-point atomics (the rows are cleared first unless RT_FLAG_ACCUMULATE).  One kernel, asynchronous on params->stream unless
  * `stats` is non-NULL, in which case the call synchronises the stream and fills *stats (= rt_render_wait).  The scene's device must be
  * the current one.  A scene has ONE set of counters and events: a second rt_render before the first one's rt_render_wait is refused
  * (RT_EINVAL).  With RT_FLAG_WAVEFRONT the call
