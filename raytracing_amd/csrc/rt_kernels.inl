@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstddef>
+#include <cstdlib>
 #include <vector>
 #include "rt_launch.h"
 #ifdef RT_WITH_WAVE
@@ -26,10 +27,19 @@ struct LdsConfigured {
 };
 
 #ifdef RT_WITH_WAVE
-// one variant of the wave kernel (rt_wave.h); more than 48 KiB of dynamic LDS needs the attribute set once per kernel
+// one variant of the wave kernel (rt_wave.h); more than 48 KiB of dynamic LDS needs the attribute set once per kernel.  one_wave: the
+// one-wave-workgroup twin (kernels without tile sums; its LDS is a quarter, far below 48 KiB)
 template <typename R, bool kQuant, int kFull>
-hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters)
+hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, bool one_wave = false)
 {
+    if constexpr (wave_global_sums<R, kFull>()) {
+        if (one_wave) {
+            if (lds > 48 * 1024) return hipErrorInvalidValue;
+            if (count) hipLaunchKernelGGL((render_wave1_kernel<R, true, kQuant, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave1_kernel<R, false, kQuant, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
+            return hipGetLastError();
+        }
+    }
     if (lds > 48 * 1024) {
         static LdsConfigured done;
         std::atomic<size_t>* configured = done.of_current_device();
@@ -48,8 +58,16 @@ hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const S
 
 // ... and its twin that visits the wide nodes' hit children by entry distance (Scene::sorted_visit)
 template <typename R, int kFull>
-hipError_t launch_wave_sorted(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters)
+hipError_t launch_wave_sorted(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, bool one_wave = false)
 {
+    if constexpr (wave_global_sums<R, kFull>()) {
+        if (one_wave) {
+            if (lds > 48 * 1024) return hipErrorInvalidValue;
+            if (count) hipLaunchKernelGGL((render_wave1_sorted_kernel<R, true, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
+            else hipLaunchKernelGGL((render_wave1_sorted_kernel<R, false, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
+            return hipGetLastError();
+        }
+    }
     if (lds > 48 * 1024) {
         static LdsConfigured done;
         std::atomic<size_t>* configured = done.of_current_device();
@@ -103,16 +121,24 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
     int trav = 0;
 #ifdef RT_WITH_WAVE
     if (a.bvh_stack_levels > 0) { trav = 2; region = (size_t) a.bvh_stack_levels * 256 * sizeof(uint32_t); }
+    // the OBJ-loader wave kernels keep no tile sums (rt_wave.h wave_global_sums); launches of few samples per pixel take their one-wave-workgroup
+    // twins over the quarters of a tile: a quarter of the stack region each, four times the workgroups
+    const bool global_sums = trav == 2 && a.kinds == 3 && !(a.flags & RT_FLAG_LEGACY_LOOP) && !(a.q_slots > 0 && q_pools && q_locks);
+    int one_wave_spp = 32;
+    if (const char* e = std::getenv("RT_ONE_WAVE_SPP")) one_wave_spp = std::atoi(e);
+    const bool one_wave = global_sums && a.spp_end - a.spp_begin <= one_wave_spp;
+    if (one_wave) { region /= 4; grid = dim3(grid.x * 4u); }
 #endif
     if (trav == 0 && a.lds_ops_bytes + a.lds_prims_bytes > 0) { trav = 1; region = (size_t) a.lds_ops_bytes + a.lds_prims_bytes; }
-    // (the fp64 OBJ-loader wave kernels keep no tile sums: rt_wave.h wave_global_sums)
-    const bool global_sums = trav == 2 && a.kinds == 3 && !(a.flags & RT_FLAG_LEGACY_LOOP) && !(a.q_slots > 0 && q_pools && q_locks);
+#ifndef RT_WITH_WAVE
+    const bool global_sums = false, one_wave = false;
+#endif
     const size_t tile_bytes = global_sums ? 16 : (sizeof(RT_REAL) == sizeof(float) || trav == 2) ? 768 * sizeof(RT_REAL) + 16 : 0;
     a.lds_tile_offset = (uint32_t) region;
     const size_t lds = region + tile_bytes;
 #ifdef RT_WITH_WAVE
     if (trav == 2 && !(a.flags & RT_FLAG_LEGACY_LOOP)) {
-        if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64)); }
+        if (a.xcd_tiles) { const int supers = ((tiles_x + 7) / 8) * ((tiles_y + 7) / 8); grid = dim3((unsigned) ((supers + 7) / 8 * 8 * 64 * (one_wave ? 4 : 1))); }
         if (a.q_slots > 0 && q_pools && q_locks && (a.kinds == 0 || a.kinds == 3)) {          // decoupled kernel (rt_queue.h): two more KiB of LDS for the lists
             const size_t qlds = lds + 16 + 4 * RT_Q_SLOTS_MAX;
             if (a.kinds == 3) {
@@ -132,9 +158,9 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
                 const hipError_t e = hipMemsetAsync(accum + (size_t) a.y_begin * a.width * 3, 0, (size_t) (a.y_end - a.y_begin) * a.width * 3 * sizeof(RT_REAL), s);
                 if (e != hipSuccess) return e;
             }
-            if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 3>(count, grid, lds, s, sc, a, accum, counters);
-            if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters);
-            return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters);
+            if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
+            if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
+            return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
         }
         if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 0>(count, grid, lds, s, sc, a, accum, counters);
         if (a.quantised) return launch_wave<RT_REAL, true, 0>(count, grid, lds, s, sc, a, accum, counters);

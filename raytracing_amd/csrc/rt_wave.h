@@ -154,8 +154,9 @@ template <typename R> __device__ inline void slab_wide(const WNode& n, const Tra
 }
 
 // One node visit of one lane: test the children's boxes, go on with the nearest one hit and push the others (farthest first), or
-// pop.  kQuant: four-wide quantised nodes (WNode), else the binary fp32 nodes (BNode).  stack_at(address) names an LDS stack entry.
-template <typename R, bool kQuant, bool kCount, bool kSorted = false, typename StackAt>
+// pop.  kQuant: four-wide quantised nodes (WNode), else the binary fp32 nodes (BNode).  stack_at(address) names an LDS stack entry;
+// kStride: bytes between a lane's stack levels (4 x the workgroup's threads).
+template <typename R, bool kQuant, bool kCount, bool kSorted = false, uint32_t kStride = 1024u, typename StackAt>
 __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, StackAt&& stack_at, VisitStats& vs)
 {
     if constexpr (kQuant) {
@@ -185,11 +186,11 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
             t4[i] = ti; t4[j] = tj; c4[i] = ci; c4[j] = cj;
         };
         order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);
-        if (t4[3] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[3]; }
-        if (t4[2] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[2]; }
-        if (t4[1] < __builtin_inff()) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c4[1]; }
+        if (t4[3] < __builtin_inff()) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c4[3]; }
+        if (t4[2] < __builtin_inff()) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c4[2]; }
+        if (t4[1] < __builtin_inff()) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c4[1]; }
         if (t4[0] < __builtin_inff()) tv.cur = c4[0];
-        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= kStride; }
         }
         else {
         const uint32_t flip = __builtin_amdgcn_perm(tv.sg, tv.sg, n.n);
@@ -200,11 +201,11 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
         const bool rev = flip != 0u;
         const int32_t c0 = rev ? n.child[3] : n.child[0], c1 = rev ? n.child[2] : n.child[1], c2 = rev ? n.child[1] : n.child[2], c3 = rev ? n.child[0] : n.child[3];
         // the children behind the first one hit wait on the stack, the last to be visited pushed first
-        if (h[3] && (h[0] || h[1] || h[2])) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c3; }
-        if (h[2] && (h[0] || h[1])) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c2; }
-        if (h[1] && h[0]) { tv.sp += 1024u; stack_at(tv.sp) = (uint32_t) c1; }
+        if (h[3] && (h[0] || h[1] || h[2])) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c3; }
+        if (h[2] && (h[0] || h[1])) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c2; }
+        if (h[1] && h[0]) { tv.sp += kStride; stack_at(tv.sp) = (uint32_t) c1; }
         if (h[0] || h[1] || h[2] || h[3]) tv.cur = h[0] ? c0 : h[1] ? c1 : h[2] ? c2 : c3;
-        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= kStride; }
         }
         RT_ASM_MARK("; wide node_step end");
     }
@@ -219,12 +220,12 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
             const bool left_first = tl <= tr;
             const int32_t far = left_first ? n.right : n.left;
             tv.cur = left_first ? n.left : n.right;
-            tv.sp += 1024u;
+            tv.sp += kStride;
             stack_at(tv.sp) = (uint32_t) far;
         }
         else if (hl) tv.cur = n.left;
         else if (hr) tv.cur = n.right;
-        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u; }
+        else { tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= kStride; }
     }
 }
 
@@ -235,25 +236,37 @@ __device__ inline void node_step(const Scene<R>& sc, Trav& tv, float t_min, Stac
 // in its XCD's L2.  (LDS sums were already added in whatever order the waves finished: no order is lost.)  10 M-triangle soup: fp64
 // 0.91 -> 1.11 Grays/s, fp32 0.98 -> 1.22; mesh fp64 unchanged, fp32 +2 % time.
 template <typename R, int kFull> constexpr bool wave_global_sums() { return class_is_obj(kFull); }
+// ... and with no sums to share, nothing ties four waves into a workgroup: these kernels have a twin that runs as ONE-WAVE workgroups over
+// 8 x 8 pixels (a quarter of a tile, render_wave1_kernel / render_wave1_sorted_kernel), each with its own pool of items and its own 256 B
+// per level of stack.  A finished wave frees its slot and its LDS at once, and the per-launch fixed cost -- every workgroup's wait for its
+// pool's longest paths, proportional to the pool -- falls (pools four times LARGER were measured the other way: +5..11 %, HISTORY).  The
+// quarters of a tile land on different CUs, though, and no longer share an L1: mesh 4K fp64 16 / 64 / 128 / 256 spp 20.4 / 70.8 / 139.9 / 274.8 ms
+// with four-wave workgroups, 19.9 / 71.4 / 142.3 / 279.4 with one-wave ones; 10 M-triangle soup at 16 spp 235.9 -> 223.7 ms.  launch_render
+// takes the twin for launches of at most RT_ONE_WAVE_SPP (32) samples per pixel.
 
 // waves per SIMD a variant is compiled for
 template <typename R, int kFull> constexpr int wave_kernel_waves()
 { return sizeof(R) == 8 ? (kFull == 3 ? RT_WAVES_FP64_OBJ : kFull == 5 ? RT_WAVES_FP64_SPHERES : kFull == 6 ? RT_WAVES_FP64_BOXES : RT_WAVES_FP64) : kFull == 3 ? RT_WAVES_OBJ : kFull == 5 ? RT_WAVES_SPHERES : RT_WAVES_FP32; }
 
-template <typename R, bool kCount, bool kQuant, int kFull, bool kSorted>
+template <typename R, bool kCount, bool kQuant, int kFull, bool kSorted, bool kOneWave = false>
 __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const RenderArgs& a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     // Workgroups go to the 8 XCDs round-robin by blockIdx, and each XCD has an L2 of its own: with xcd_tiles set, the image is cut
     // into super-tiles of 8 x 8 tiles, dealt to the XCDs round-robin (neighbouring super-tiles cost about the same, so the XCDs
     // stay balanced), and the tiles an XCD has in flight are two or three compact 128 x 128-pixel blocks rather than every
     // eighth tile of a strip across the image
+    constexpr bool kGlobalSums = wave_global_sums<R, kFull>();
+    static_assert(!kOneWave || kGlobalSums, "one-wave workgroups: kernels without tile sums only");
+    constexpr uint32_t kStride = kOneWave ? 256u : 1024u;     // bytes between a lane's stack levels (4 x the workgroup's threads)
     const int tiles_x = (a.width + 15) >> 4;
-    int tile_x, tile_y;
+    int tile_x, tile_y, sub = 0;
     uint32_t unit;                                                            // the scheduling unit this workgroup belongs to (RenderArgs::unit_order)
     if (a.xcd_tiles) {
         const int tiles_y = (a.y_end - a.y_begin + 15) >> 4;
         const int stx = (tiles_x + 7) >> 3, sty = (tiles_y + 7) >> 3;
-        const int s = (int) (blockIdx.x >> 3), slot = (s >> 6) * 8 + (int) (blockIdx.x & 7u), within = s & 63;
+        // (one-wave workgroups: four per tile, `sub` = which 8 x 8 quarter)
+        const int s = (int) (blockIdx.x >> 3) >> (kOneWave ? 2 : 0), slot = (s >> 6) * 8 + (int) (blockIdx.x & 7u), within = s & 63;
+        sub = kOneWave ? (int) ((blockIdx.x >> 3) & 3u) : 0;
         if (slot >= stx * sty) return;                                        // grid padding (whole workgroup, before any barrier)
         const int super = a.unit_order ? (int) a.unit_order[slot] : slot;
         const int sy = super / stx, sx = super - sy * stx;
@@ -262,7 +275,9 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
         unit = (uint32_t) super;
     }
     else {
-        unit = a.unit_order ? a.unit_order[blockIdx.x] : blockIdx.x;
+        const uint32_t tile_slot = kOneWave ? blockIdx.x >> 2 : blockIdx.x;
+        sub = kOneWave ? (int) (blockIdx.x & 3u) : 0;
+        unit = a.unit_order ? a.unit_order[tile_slot] : tile_slot;
         tile_x = (int) (unit % (unsigned) tiles_x); tile_y = (int) (unit / (unsigned) tiles_x);
     }
     extern __shared__ __align__(16) unsigned char smem[];
@@ -271,7 +286,6 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     const uint32_t stack_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) smem + threadIdx.x * 4u;
     auto stack_at = [&](uint32_t lds_address) -> lds_u32& { return *(lds_u32*) (uintptr_t) lds_address; };
-    constexpr bool kGlobalSums = wave_global_sums<R, kFull>();
     R* tile_sum = reinterpret_cast<R*>(smem + a.lds_tile_offset);
     unsigned int* item_counter = reinterpret_cast<unsigned int*>(tile_sum + (kGlobalSums ? 0 : 768));
     if constexpr (!kGlobalSums) { tile_sum[threadIdx.x * 3] = R(0); tile_sum[threadIdx.x * 3 + 1] = R(0); tile_sum[threadIdx.x * 3 + 2] = R(0); }
@@ -280,12 +294,13 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    auto pixel_of = [&](int local, int& jj, int& ii) {       // slot 0..255 of the 16x16 tile: waves are 8x8 sub-tiles
-        const int wv = local >> 6, ln = local & 63;
+    auto pixel_of = [&](int local, int& jj, int& ii) {       // slot 0..255 of the 16x16 tile: waves are 8x8 sub-tiles (one-wave workgroups: slot 0..63 of quarter `sub`)
+        const int wv = kOneWave ? sub : local >> 6, ln = local & 63;
         jj = tile_x * 16 + (wv & 1) * 8 + (ln & 7);
         ii = a.y_begin + tile_y * 16 + (wv >> 1) * 8 + (ln >> 3);
     };
-    const unsigned int n_items = 256u * (unsigned int) (a.spp_end - a.spp_begin);
+    constexpr unsigned int kSlots = kOneWave ? 64u : 256u, kSlotBits = kOneWave ? 6u : 8u;
+    const unsigned int n_items = kSlots * (unsigned int) (a.spp_end - a.spp_begin);
     const float t_min = consts<float>::tmin;          // box culling; primitive tests take consts<R>::tmin
     const Prim<R>* __restrict__ fprims = sc.fprims;
     const int trav_keep = (int) a.trav_keep, node_keep = (int) a.node_keep, regen_min = (int) a.regen_min;
@@ -316,7 +331,7 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
             RT_ASM_MARK("; regenerate begin");
             if (!alive && !finished) {
                 // one LDS atomic per wave: the first fetching lane reserves a run of items for all fetching lanes; item =
-                // sample * 256 + slot, so simultaneous fetches are neighbouring pixels of one sample
+                // sample * (slots of the workgroup) + slot, so simultaneous fetches are neighbouring pixels of one sample
                 const int leader = __ffsll(want) - 1;
                 unsigned int base = 0;
                 if (lane == leader) base = atomicAdd(item_counter, (unsigned int) __popcll(want));
@@ -325,8 +340,8 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                 const unsigned int item = base + __builtin_amdgcn_mbcnt_hi((unsigned int) (want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) want, 0u));
                 if (item >= n_items) finished = true;
                 else {
-                    local = (int) (item & 255u);
-                    const int k = a.spp_begin + (int) (item >> 8);
+                    local = (int) (item & (kSlots - 1u));
+                    const int k = a.spp_begin + (int) (item >> kSlotBits);
                     int j, i;
                     pixel_of(local, j, i);
                     if (j < a.width && i < a.y_end) {                                         // else: slot outside the image (edge tiles)
@@ -362,7 +377,7 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                     const unsigned c2 = (unsigned) __popcll(__ballot(!alive));
                     census[0] += c0; census[1] += c1; census[2] += c2;
                 }
-                if (tv.cur >= 0) node_step<R, kQuant, kCount, kSorted>(sc, tv, t_min, stack_at, vs);
+                if (tv.cur >= 0) node_step<R, kQuant, kCount, kSorted, kStride>(sc, tv, t_min, stack_at, vs);
             }
             lap(1);
             // leaves
@@ -398,7 +413,7 @@ __device__ __forceinline__ void render_wave_body(const Scene<R>& sc, const Rende
                     asm volatile("" : "+v"(rec.g[0]), "+v"(rec.g[4]), "+v"(rec.g[8]), "+v"(rec.id));
                     if (prim_t<R, kFull>(rec, sc.side(), ray, consts<R>::tmin, closest_of(tv, best), t, &g) && take_hit(sc, t, closest_of(tv, best), tv.hit, rec.id)) { set_closest(tv, best, t); tv.hit = first + k; }
                 }
-                tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= 1024u;
+                tv.cur = (int32_t) stack_at(tv.sp); tv.sp -= kStride;
                 RT_ASM_MARK("; leaf step end");
             }
             lap(2);
@@ -575,6 +590,17 @@ template <typename R, bool kCount, int kFull>
 __global__ void __launch_bounds__(256, (sizeof(R) == 8 && kFull == 3 ? RT_WAVES_FP64_SORTED : wave_kernel_waves<R, kFull>())) render_wave_sorted_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
 {
     render_wave_body<R, kCount, true, kFull, true>(sc, a, accum, counters);
+}
+// ... and their one-wave-workgroup twins (kernels without tile sums: wave_global_sums), for launches of few samples per pixel
+template <typename R, bool kCount, bool kQuant, int kFull>
+__global__ void __launch_bounds__(64, (wave_kernel_waves<R, kFull>())) render_wave1_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    render_wave_body<R, kCount, kQuant, kFull, false, true>(sc, a, accum, counters);
+}
+template <typename R, bool kCount, int kFull>
+__global__ void __launch_bounds__(64, (sizeof(R) == 8 && kFull == 3 ? RT_WAVES_FP64_SORTED : wave_kernel_waves<R, kFull>())) render_wave1_sorted_kernel(Scene<R> sc, RenderArgs a, R* __restrict__ accum, unsigned long long* __restrict__ counters)
+{
+    render_wave_body<R, kCount, true, kFull, true, true>(sc, a, accum, counters);
 }
 
 // Closest hit of explicit rays through the fast tree, with the render kernel's own culling code (trav_begin, node_step: slab_fma / slab_wide,

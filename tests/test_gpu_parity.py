@@ -493,6 +493,36 @@ def test_quantised_nodes_same_frame(R, golden_dir, monkeypatch):
     osc.free()
 
 
+@pytest.mark.parametrize("mode_name", ["MODE_FAST_FP64", "MODE_FAST_FP32"])
+@pytest.mark.parametrize("w,h,rows", [(60, 40, (0, 40)), (200, 120, (16, 99))])
+def test_one_wave_and_four_wave_workgroups_render_the_same_frame(R, golden_dir, monkeypatch, mode_name, w, h, rows):
+    """Triangle scenes keep no tile sums in LDS (finished paths go to the frame buffer with atomics), and launches of few samples per
+    pixel run as one-wave workgroups over the quarters of a tile (render_wave1_kernel) instead of four-wave ones over whole tiles.  Which
+    of the two a launch takes (RT_ONE_WAVE_SPP moves the limit) must not show: the same samples land on the same pixels -- per-pixel ray
+    and rejected-sample counts identical (RT_FLAG_DEBUG_RAY_COUNTS), frames equal to the rounding of the additions, also on ragged sizes,
+    a row range, an accumulating second call, and with the XCD super-tile order forced on."""
+    g, m = load(golden_dir, "obj")
+    osc = SCENES["obj"][1](golden_dir, m)
+    osc.set_size(w, h)
+    mode = getattr(R, mode_name)
+    for xcd in ("0", "1"):
+        monkeypatch.setenv("RT_XCD_TILES", xcd)
+        sc = R.Scene(osc.export())
+        out = []
+        for limit in ("0", "100000"):
+            monkeypatch.setenv("RT_ONE_WAVE_SPP", limit)
+            counts, _, sa = sc.render_to_host(w, h, 0, 6, 12, mode, seed=3, flags=R.FLAG_DEBUG_RAY_COUNTS, y_begin=rows[0], y_end=rows[1])
+            frame, _, sb = sc.render_to_host(w, h, 0, 6, 12, mode, seed=3, y_begin=rows[0], y_end=rows[1])
+            out.append((counts, frame, sa["rays"], sb["rays"]))
+        (ca, fa, ra, rb), (cb, fb, rc, rd) = out
+        assert ra == rc and rb == rd and ra == rb
+        assert np.array_equal(ca, cb)
+        assert float(np.abs(fa - fb).max()) <= (1e-12 if mode_name.endswith("64") else 1e-4) * max(float(np.abs(fa).max()), 1.0)
+        assert not fa[:rows[0]].any() and not fa[rows[1]:].any() and fa[rows[0]:rows[1]].any()
+        sc.destroy()
+    osc.free()
+
+
 def test_triangle_scene_with_a_checker_takes_the_general_kernel(R, golden_dir):
     """The OBJ-loader kernel variant (class 3) is compiled without the checker texture's code: the loader never makes one.  A description
     that does hold one -- triangles, phong materials and a checker on one of them -- must fall to the general variant and render what
