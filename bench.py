@@ -353,6 +353,10 @@ def main():
         valu_frac = time_at_peak / secs
         # OBJ-loader scenes (triangles + phong only) walk the quantised four-wide nodes by default (rtcore.hip, RT_QNODES overrides)
         kernel_name = scene.kernel_name(mode)
+        # launches of at most 32 samples per pixel of a triangle scene take the one-wave-workgroup twin of that kernel (rt_wave.h render_wave1_*;
+        # RT_ONE_WAVE_SPP moves the limit): name the kernel this run's launches used
+        if k1 - k0 <= int(os.environ.get("RT_ONE_WAVE_SPP", "32")) and kernel_name.rstrip(">").endswith(" 3") and "render_wave_" in kernel_name:
+            kernel_name = kernel_name.replace("render_wave_", "render_wave1_")
         # render_wave_kernel<R, count, wide nodes, scene class>; render_wave_sorted_kernel<R, count, scene class> always walks the wide nodes
         quantised = fast and ("render_wave_sorted_kernel" in kernel_name or kernel_name.split(",")[2].strip() == "true")
         # a fast-mode node record is 64 B and holds its children's boxes: four quantised ones or two fp32 ones

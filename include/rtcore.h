@@ -209,7 +209,8 @@ int rt_render_wait(rt_scene* scene, rt_render_stats* stats);
 
 /* The name (as rocprofv3 lists it, without the argument list) of the kernel an rt_render of this scene with this mode and flags launches:
  * the render kernels are compiled in variants by scene content and node format, and a profile is only comparable with a run of the same
- * variant.  No counterpart in the reference.  Host only. */
+ * variant.  (Scenes of triangles alone: a launch of at most 32 samples per pixel takes that kernel's one-wave-workgroup twin, named
+ * render_wave1_... instead of render_wave_...)  No counterpart in the reference.  Host only. */
 int rt_render_kernel_name(rt_scene* scene, int mode, int flags, char* out, size_t out_bytes);
 
 /* One process, several GPUs (no counterpart in the reference, which knows one device): the spp split of SURVEY 8e at the C boundary.
