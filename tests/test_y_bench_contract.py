@@ -47,7 +47,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields(R):
     assert d["config"]["rays_per_step"] <= d["config"]["reference_rays_per_step"] and d["value"] <= d["value_reference_ray_count"]
     share = 1.0 - d["config"]["rays_per_step"] / d["config"]["reference_rays_per_step"]
     assert abs(share - d["config"]["zero_direction_ray_share"]) < 0.02, "in a scene of triangles alone every zero-direction ray is finished without a traversal"
-    assert r["kernel"].startswith("rt::render_wave_kernel<double, false, ")
+    assert r["kernel"].startswith("rt::render_wave1_kernel<double, false, "), r["kernel"]      # 8 spp: the one-wave-workgroup twin of the triangle-scene kernel
     assert d["fp32_mode"]["dtype"] == "f32" and d["fp32_mode"]["value"] > 0
 
 
