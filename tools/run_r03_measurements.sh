@@ -1,4 +1,6 @@
 # Round-3 measurements on the GPU box.  usage: bash tools/run_r03_measurements.sh <tag> <part: bench|pmc|pmc_sorted|spheres>
+# (the 10 M-triangle soup has scripts of its own -- its host-side build outlasts gpurun's silence limit without a heartbeat: tools/bench_soup.sh,
+# tools/pmc_soup_traffic.sh; memory latency and cache hit rates of the mesh kernel: tools/pmc_latency.sh; summaries into profiles/: tools/collect_r03.py)
 # Every profiled command is `python3 bench.py ...` itself after `--` (no shell or env hop under rocprofv3); PMC passes are separate runs.
 set -e
 export TMPDIR=/tmp
