@@ -7,83 +7,13 @@
 #include "rt_launch.h"
 #ifdef RT_WITH_WAVE
 #include "rt_wave.h"
+#include "rt_wave_launch.h"
 #include "rt_queue.h"
 #endif
 
 namespace rt {
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: a process that drives several devices (rt_device_set,
-// scene::render(..., devices)) must set it on each of them.  One instance per kernel variant remembers the largest size set so far per
-// device (atomics: renders of different scenes may be launched from different host threads; setting the attribute twice is harmless).
-struct LdsConfigured {
-    static constexpr int kMaxDevices = 64;
-    std::atomic<size_t> bytes[kMaxDevices] = {};
-    std::atomic<size_t>* of_current_device()
-    {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-        return &bytes[dev];
-    }
-};
-
 #ifdef RT_WITH_WAVE
-// one variant of the wave kernel (rt_wave.h); more than 48 KiB of dynamic LDS needs the attribute set once per kernel.  one_wave: the
-// one-wave-workgroup twin (kernels without tile sums; its LDS is a quarter, far below 48 KiB)
-template <typename R, bool kQuant, int kFull>
-hipError_t launch_wave(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, bool one_wave = false)
-{
-    if constexpr (wave_global_sums<R, kFull>()) {
-        if (one_wave) {
-            if (lds > 48 * 1024) return hipErrorInvalidValue;
-            if (count) hipLaunchKernelGGL((render_wave1_kernel<R, true, kQuant, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave1_kernel<R, false, kQuant, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
-            return hipGetLastError();
-        }
-    }
-    if (lds > 48 * 1024) {
-        static LdsConfigured done;
-        std::atomic<size_t>* configured = done.of_current_device();
-        if (!configured) return hipErrorInvalidDevice;
-        if (lds > configured->load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, false, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_kernel<R, true, kQuant, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-            configured->store(lds, std::memory_order_relaxed);
-        }
-    }
-    if (count) hipLaunchKernelGGL((render_wave_kernel<R, true, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
-    else hipLaunchKernelGGL((render_wave_kernel<R, false, kQuant, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
-    return hipGetLastError();
-}
-
-// ... and its twin that visits the wide nodes' hit children by entry distance (Scene::sorted_visit)
-template <typename R, int kFull>
-hipError_t launch_wave_sorted(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, bool one_wave = false)
-{
-    if constexpr (wave_global_sums<R, kFull>()) {
-        if (one_wave) {
-            if (lds > 48 * 1024) return hipErrorInvalidValue;
-            if (count) hipLaunchKernelGGL((render_wave1_sorted_kernel<R, true, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
-            else hipLaunchKernelGGL((render_wave1_sorted_kernel<R, false, kFull>), grid, dim3(64), lds, s, sc, a, accum, counters);
-            return hipGetLastError();
-        }
-    }
-    if (lds > 48 * 1024) {
-        static LdsConfigured done;
-        std::atomic<size_t>* configured = done.of_current_device();
-        if (!configured) return hipErrorInvalidDevice;
-        if (lds > configured->load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_sorted_kernel<R, false, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_wave_sorted_kernel<R, true, kFull>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-            configured->store(lds, std::memory_order_relaxed);
-        }
-    }
-    if (count) hipLaunchKernelGGL((render_wave_sorted_kernel<R, true, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
-    else hipLaunchKernelGGL((render_wave_sorted_kernel<R, false, kFull>), grid, dim3(256), lds, s, sc, a, accum, counters);
-    return hipGetLastError();
-}
-
 // one variant of the decoupled kernel (rt_queue.h)
 template <typename R, bool kQuant, int kFull>
 hipError_t launch_queue(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<R>& sc, const RenderArgs& a, R* accum, unsigned long long* counters, void* pools, unsigned int* locks)
@@ -158,9 +88,13 @@ hipError_t launch_render(const Scene<RT_REAL>& sc, const RenderArgs& a_in, RT_RE
                 const hipError_t e = hipMemsetAsync(accum + (size_t) a.y_begin * a.width * 3, 0, (size_t) (a.y_end - a.y_begin) * a.width * 3 * sizeof(RT_REAL), s);
                 if (e != hipSuccess) return e;
             }
+#ifdef RT_OBJ_WAVE_KERNELS_ELSEWHERE      // fp64: those kernels live in rt_kernels_fp64_obj.hip
+            return launch_wave_obj(count, grid, lds, s, sc, a, accum, counters, one_wave);
+#else
             if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
             if (a.quantised) return launch_wave<RT_REAL, true, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
             return launch_wave<RT_REAL, false, 3>(count, grid, lds, s, sc, a, accum, counters, one_wave);
+#endif
         }
         if (a.quantised && sc.sorted_visit) return launch_wave_sorted<RT_REAL, 0>(count, grid, lds, s, sc, a, accum, counters);
         if (a.quantised) return launch_wave<RT_REAL, true, 0>(count, grid, lds, s, sc, a, accum, counters);

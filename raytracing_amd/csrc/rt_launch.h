@@ -9,6 +9,8 @@ namespace rt {
 // q_pools / q_locks: path pools and their locks for the decoupled kernel (rt_queue.h), used when a.q_slots > 0; may be null otherwise
 hipError_t launch_render(const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, hipStream_t s, void* q_pools = nullptr, unsigned int* q_locks = nullptr);
 hipError_t launch_render(const Scene<float>& sc, const RenderArgs& a, float* accum, unsigned long long* counters, hipStream_t s, void* q_pools = nullptr, unsigned int* q_locks = nullptr);
+// the fp64 OBJ-loader wave kernels (their own translation unit, rt_kernels_fp64_obj.hip): the variant by node format and visiting order
+hipError_t launch_wave_obj(bool count, dim3 grid, size_t lds, hipStream_t s, const Scene<double>& sc, const RenderArgs& a, double* accum, unsigned long long* counters, bool one_wave);
 size_t queue_slot_bytes(double);
 size_t queue_slot_bytes(float);
 // RT_MODE_FAST_FP32: wavefront loop over a path pool (rt_wavefront.h).  Blocks until the frame's samples are done; fills

@@ -11,6 +11,7 @@ S=raytracing_amd/csrc
 $C -c $S/rtcore.hip -o $D/rtcore.o &
 $C -ffp-contract=off -c $S/rt_kernels_fp64.hip -o $D/rt_kernels_fp64.o -Rpass-analysis=kernel-resource-usage 2> $D/usage64.txt &
 $C -fno-hip-fp32-correctly-rounded-divide-sqrt -c $S/rt_kernels_fp32.hip -o $D/rt_kernels_fp32.o &
+$C -ffp-contract=off -mllvm -amdgpu-sched-strategy=max-ilp -c $S/rt_kernels_fp64_obj.hip -o $D/rt_kernels_fp64_obj.o -Rpass-analysis=kernel-resource-usage 2> $D/usage64_obj.txt &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/librtcore_$NAME.so $D/rtcore.o $D/rt_kernels_fp64.o $D/rt_kernels_fp32.o
-python3 tools/kernel_usage.py $D/usage64.txt "render_wave_kernel<double, false, true, 3>"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/librtcore_$NAME.so $D/rtcore.o $D/rt_kernels_fp64.o $D/rt_kernels_fp64_obj.o $D/rt_kernels_fp32.o
+python3 tools/kernel_usage.py $D/usage64_obj.txt "render_wave_kernel<double, false, true, 3>"
